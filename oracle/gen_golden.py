@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE ITSELF.
+
+Runs only in the build container (imports /root/reference, which never travels
+to the GPU box).  The outputs are data only -- inputs (camera, config, ids) and
+expected outputs (iteration maps, hit masks, depths, stats scalars).
+
+For every (scene, strategy) the scene/strategy/camera/Lipschitz wiring follows
+run_once (reference main.py:39-74) with a FRESH RenderConfig, and the pixel loop
+follows MetricsCollector.benchmark_strategy (metrics/collector.py:40-44); the
+stats scalars come from the reference's own RayMarchStats.compute (core/types.py:77-137).
+
+Layout of each frames_*.npz (keys prefixed "s{scene_id}_k{strategy_id}_"):
+  iters   int16 (H,W)         exact iteration counts (max possible 521)
+  hitbits uint8 packbits(H*W) exact hit mask
+  t_hit   float64 (n_hits,)   raw t of the hit rays, row-major order
+  sha_t / sha_fs              sha256 over the little-endian float64 bytes of t / final_sdf
+                              of ALL rays (pins the oracle bit-for-bit without storing them)
+  cam     float64 (14,)       position, forward, right, up, half_width, half_height
+  meta    float64 (8,)        W, H, row0, rows, max_iterations, hit_threshold, max_distance, lipschitz
+
+Usage:  python oracle/gen_golden.py [--only frames64|frames160|rows1080|sdf|stats|leak]
+"""
+from __future__ import annotations
+
+import argparse
+import hashlib
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+
+from raymarching_benchmark.config import MarchConfig, RenderConfig  # noqa: E402
+from raymarching_benchmark.core.camera import Camera  # noqa: E402
+from raymarching_benchmark.core.types import RayMarchStats  # noqa: E402
+from raymarching_benchmark.core.vec3 import Vec3  # noqa: E402
+from raymarching_benchmark.scenes.catalog import get_all_scenes  # noqa: E402
+from raymarching_benchmark.strategies import STRATEGIES  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+SCENES = get_all_scenes()
+STRAT_KEYS = list(STRATEGIES.keys())
+
+
+def wire(scene_id: int, strat_id: int, width: int, height: int, render: RenderConfig | None = None):
+    """run_once's wiring (main.py:39-74) for registry ids."""
+    scene = get_all_scenes()[scene_id]
+    strategy = STRATEGIES[STRAT_KEYS[strat_id]]()
+    render = render or RenderConfig(width=width, height=height)
+    sug = scene.suggested_camera()
+    if sug:
+        render.camera_position = sug.camera_position
+        render.camera_target = sug.camera_target
+        render.camera_up = sug.camera_up
+        render.fov_degrees = sug.fov_degrees
+    lipschitz = 1.0
+    if hasattr(strategy, "lipschitz"):
+        bound = scene.known_lipschitz_bound()
+        if bound is not None:
+            strategy.lipschitz = bound
+        lipschitz = float(strategy.lipschitz)
+    cam = Camera(position=Vec3(*render.camera_position), target=Vec3(*render.camera_target),
+                 up=Vec3(*render.camera_up), fov_degrees=render.fov_degrees,
+                 width=render.width, height=render.height)
+    return scene, strategy, cam, lipschitz, render
+
+
+def cam14(cam: Camera) -> np.ndarray:
+    return np.array([*cam.position.to_tuple(), *cam.forward.to_tuple(), *cam.right.to_tuple(),
+                     *cam.up.to_tuple(), cam.half_width, cam.half_height], dtype=np.float64)
+
+
+def march_rows(scene, strategy, cam, mc, row0, rows):
+    results = []
+    for py in range(row0, row0 + rows):
+        for px in range(cam.width):
+            results.append(strategy.march(cam.get_ray(px, py), scene.sdf, mc))
+    return results
+
+
+def pack(prefix, results, cam, mc, lipschitz, row0, rows, store):
+    W = cam.width
+    iters = np.array([r.iterations for r in results], dtype=np.int32).reshape(rows, W)
+    hit = np.array([bool(r.hit) for r in results], dtype=bool)
+    t = np.array([float(r.t) for r in results], dtype="<f8")
+    fs = np.array([float(r.final_sdf) for r in results], dtype="<f8")
+    assert iters.max() < 32767
+    store[prefix + "iters"] = iters.astype(np.int16)
+    store[prefix + "hitbits"] = np.packbits(hit)
+    store[prefix + "t_hit"] = t[hit]
+    store[prefix + "sha_t"] = np.frombuffer(hashlib.sha256(t.tobytes()).digest(), dtype=np.uint8)
+    store[prefix + "sha_fs"] = np.frombuffer(hashlib.sha256(fs.tobytes()).digest(), dtype=np.uint8)
+    store[prefix + "cam"] = cam14(cam)
+    store[prefix + "meta"] = np.array([W, cam.height, row0, rows, mc.max_iterations, mc.hit_threshold,
+                                       mc.max_distance, lipschitz], dtype=np.float64)
+
+
+def stats_dict(scene, strategy, results, W, H):
+    s = RayMarchStats(strategy_name=strategy.short_name, scene_name=scene.name)
+    s.compute(results, W, H, 1.0)
+    return {
+        "strategy": s.strategy_name, "scene": s.scene_name, "total_rays": s.total_rays,
+        "hit_count": s.hit_count, "miss_count": s.miss_count, "sample_count": s.sample_count,
+        "iteration_mean": s.iteration_mean, "iteration_median": s.iteration_median,
+        "iteration_std": s.iteration_std, "iteration_min": s.iteration_min,
+        "iteration_max": s.iteration_max, "iteration_p95": s.iteration_p95,
+        "iteration_p99": s.iteration_p99, "accuracy_mean": s.accuracy_mean,
+        "accuracy_max": s.accuracy_max, "accuracy_std": s.accuracy_std, "hit_rate": s.hit_rate,
+        "warp_divergence_proxy": s.warp_divergence_proxy,
+        "depth_sum": float(s.depth_map.sum()),
+    }
+
+
+def gen_frames(tag, W, H, pairs, mc=None):
+    mc = mc or MarchConfig()
+    store, stats = {}, {}
+    t0 = time.time()
+    for sid, kid in pairs:
+        scene, strategy, cam, lip, _ = wire(sid, kid, W, H)
+        res = march_rows(scene, strategy, cam, mc, 0, H)
+        pack(f"s{sid}_k{kid}_", res, cam, mc, lip, 0, H, store)
+        stats[f"s{sid}_k{kid}"] = stats_dict(scene, strategy, res, W, H)
+        print(f"  [{tag}] {scene.name} / {strategy.short_name}: hits={stats[f's{sid}_k{kid}']['hit_count']} "
+              f"sum_iters={stats[f's{sid}_k{kid}']['sample_count']}  ({time.time() - t0:.0f}s)", flush=True)
+    np.savez_compressed(os.path.join(OUT, f"frames_{tag}.npz"), **store)
+    with open(os.path.join(OUT, f"stats_{tag}.json"), "w", encoding="utf-8") as f:
+        json.dump(stats, f, indent=1, ensure_ascii=False)
+
+
+def gen_rows1080(pairs, row0=536, rows=8):
+    """Row-block samples of the 1920x1080 frame: pins full-resolution indexing."""
+    mc = MarchConfig()
+    store = {}
+    for sid, kid in pairs:
+        scene, strategy, cam, lip, _ = wire(sid, kid, 1920, 1080)
+        res = march_rows(scene, strategy, cam, mc, row0, rows)
+        pack(f"s{sid}_k{kid}_", res, cam, mc, lip, row0, rows, store)
+        print(f"  [rows1080] {scene.name} / {strategy.short_name}", flush=True)
+    np.savez_compressed(os.path.join(OUT, "frames_rows1080.npz"), **store)
+
+
+def gen_leak():
+    """The CLI reuses one RenderConfig across scenes (main.py:167,206): a scene without a
+    suggested camera inherits the previous scene's.  Pin Cube rendered right after
+    Grazing Plane (non-default, off-axis camera)."""
+    mc = MarchConfig()
+    store = {}
+    rc = RenderConfig(width=64, height=48)
+    wire(1, 0, 64, 48, rc)  # Grazing Plane mutates rc
+    scene, strategy, cam, lip, _ = wire(2, 0, 64, 48, rc)
+    res = march_rows(scene, strategy, cam, mc, 0, 48)
+    pack("s2_k0_", res, cam, mc, lip, 0, 48, store)
+    np.savez_compressed(os.path.join(OUT, "frames_leak.npz"), **store)
+
+
+def gen_sdf(n=2000):
+    """Per-scene SDF values at seeded random points (same generator idea as the
+    reference's tests/test_scene_parity.py:88-102)."""
+    rng = random.Random(1234)
+    pts = np.array([[rng.uniform(-3.5, 3.5) for _ in range(3)] for _ in range(n)], dtype=np.float64)
+    store = {"pts": pts}
+    for sid, scene in enumerate(SCENES):
+        store[f"s{sid}"] = np.array([scene.sdf(Vec3(*p)) for p in pts], dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "sdf_points.npz"), **store)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="all")
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    all_pairs = [(s, k) for s in range(len(SCENES)) for k in range(len(STRAT_KEYS))]
+    graded9 = [0, 1, 2, 3, 4, 5, 6, 9, 10]  # the README's nine strategies (ids in STRATEGIES order)
+    if a.only in ("all", "sdf"):
+        gen_sdf()
+    if a.only in ("all", "frames64"):
+        gen_frames("64x48", 64, 48, all_pairs)
+    if a.only in ("all", "frames160"):
+        pairs = [(0, k) for k in graded9] + [(2, k) for k in graded9]
+        pairs += [(s, k) for s in (9, 10) for k in (0, 4, 6)] + [(12, 0)]
+        gen_frames("160x120", 160, 120, pairs)
+    if a.only in ("all", "rows1080"):
+        gen_rows1080([(0, 0), (2, 0), (9, 0), (10, 0), (10, 4), (10, 6), (12, 0)])
+    if a.only in ("all", "leak"):
+        gen_leak()
+    if a.only in ("all", "small"):
+        # max_iterations=100, 16x12: the configuration of the reference's own smoke test
+        # (tests/test_smoke.py:31-43), every registry key on the Sphere.
+        gen_frames("16x12_it100", 16, 12, [(0, k) for k in range(len(STRAT_KEYS))],
+                   MarchConfig(max_iterations=100))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,166 @@
+"""ctypes front-end of the CPU oracle (oracle/rm_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  Nothing under raymarch_algo_compare_amd/ imports it.
+
+Scene ids follow get_all_scenes() (reference scenes/catalog.py:640-663) and
+strategy ids follow the STRATEGIES dict order (strategies/__init__.py:16-28).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "librm_oracle.so")
+
+SCENE_NAMES = [
+    "Sphere", "Grazing Plane", "Cube", "Thin Torus", "Cylinder", "Near Miss",
+    "Hollow Cube (CSG)", "Smooth Blend", "Onion Shell", "Menger Sponge (iter=3)",
+    "Mandelbulb", "Bad Lipschitz Sphere", "Pillar Forest", "Thin Planes Stack",
+    "Sphere Cloud", "Bumpy Sphere", "Gyroid", "Capped Torus", "Box Lattice", "Metaballs",
+]
+STRATEGY_KEYS = [
+    "Standard", "Relaxed", "Heuristic-Auto-Relaxed", "Slope-Auto-Relaxed", "Enhanced",
+    "Curvature", "Overstep-Bisect", "Skipping-Spheres", "RevAA", "Adaptive-Hybrid", "Segment",
+]
+
+
+class _Cfg(ctypes.Structure):
+    _fields_ = [
+        ("max_iterations", ctypes.c_int32),
+        ("hit_threshold", ctypes.c_double),
+        ("max_distance", ctypes.c_double),
+        ("lipschitz", ctypes.c_double),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (oracle/Makefile).  Building the checker is not using it."""
+    if force or not os.path.exists(_LIB_PATH) or (
+        os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "rm_oracle.c"))
+    ):
+        subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        dp = ctypes.POINTER(ctypes.c_double)
+        L.rmo_sdf_eval.argtypes = [ctypes.c_int, dp, ctypes.c_size_t, dp]
+        L.rmo_sdf_eval.restype = ctypes.c_int
+        L.rmo_march_rays.argtypes = [
+            ctypes.c_int, ctypes.c_int, ctypes.POINTER(_Cfg), dp, dp, ctypes.c_size_t,
+            ctypes.POINTER(ctypes.c_uint8), dp, ctypes.POINTER(ctypes.c_int32), dp,
+        ]
+        L.rmo_march_rays.restype = ctypes.c_int
+        L.rmo_render.argtypes = [
+            ctypes.c_int, ctypes.c_int, ctypes.POINTER(_Cfg), dp, ctypes.c_int, ctypes.c_int,
+            ctypes.c_int, ctypes.c_int, ctypes.c_int,
+            ctypes.POINTER(ctypes.c_uint8), dp, ctypes.POINTER(ctypes.c_int32), dp,
+        ]
+        L.rmo_render.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def _dptr(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def camera14(position, target, up, fov_degrees, width, height) -> np.ndarray:
+    """Camera.__init__ restated with Python floats (reference core/camera.py:11-33,
+    core/vec3.py:46-56): position, forward, right, true_up, half_width, half_height."""
+
+    def norm(vx, vy, vz):
+        l = (vx * vx + vy * vy + vz * vz) ** 0.5
+        if l < 1e-12:
+            return (0.0, 0.0, 0.0)
+        inv = 1.0 / l
+        return (vx * inv, vy * inv, vz * inv)
+
+    def cross(a, b):
+        return (a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0])
+
+    p = tuple(float(c) for c in position)
+    tg = tuple(float(c) for c in target)
+    u = tuple(float(c) for c in up)
+    fwd = norm(tg[0] - p[0], tg[1] - p[1], tg[2] - p[2])
+    right = norm(*cross(fwd, u))
+    true_up = norm(*cross(right, fwd))
+    aspect = width / height
+    half_h = math.tan(math.radians(fov_degrees) / 2.0)
+    half_w = aspect * half_h
+    return np.array([*p, *fwd, *right, *true_up, half_w, half_h], dtype=np.float64)
+
+
+@dataclass
+class OracleFrame:
+    hit: np.ndarray        # (rows, W) uint8
+    t: np.ndarray          # (rows, W) float64, raw termination parameter of every ray
+    iters: np.ndarray      # (rows, W) int32
+    final_sdf: np.ndarray  # (rows, W) float64
+
+
+def sdf_eval(scene_id: int, pts: np.ndarray) -> np.ndarray:
+    pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
+    out = np.empty(len(pts), dtype=np.float64)
+    rc = lib().rmo_sdf_eval(scene_id, _dptr(pts), len(pts), _dptr(out))
+    if rc:
+        raise ValueError(f"rmo_sdf_eval rc={rc}")
+    return out
+
+
+def render(scene_id: int, strategy_id: int, cam14: np.ndarray, width: int, height: int,
+           row0: int = 0, rows: int | None = None, max_iterations: int = 512,
+           hit_threshold: float = 1e-4, max_distance: float = 100.0, lipschitz: float = 1.0,
+           nthreads: int = 1) -> OracleFrame:
+    rows = height - row0 if rows is None else rows
+    cfg = _Cfg(max_iterations, hit_threshold, max_distance, lipschitz)
+    n = rows * width
+    hit = np.empty(n, dtype=np.uint8)
+    t = np.empty(n, dtype=np.float64)
+    iters = np.empty(n, dtype=np.int32)
+    fs = np.empty(n, dtype=np.float64)
+    cam14 = np.ascontiguousarray(cam14, dtype=np.float64)
+    rc = lib().rmo_render(
+        scene_id, strategy_id, ctypes.byref(cfg), _dptr(cam14), width, height, row0, rows, nthreads,
+        hit.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), _dptr(t),
+        iters.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _dptr(fs),
+    )
+    if rc:
+        raise ValueError(f"rmo_render rc={rc}")
+    sh = (rows, width)
+    return OracleFrame(hit.reshape(sh), t.reshape(sh), iters.reshape(sh), fs.reshape(sh))
+
+
+def march_rays(scene_id: int, strategy_id: int, origins: np.ndarray, dirs: np.ndarray,
+               max_iterations: int = 512, hit_threshold: float = 1e-4, max_distance: float = 100.0,
+               lipschitz: float = 1.0):
+    origins = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
+    dirs = np.ascontiguousarray(dirs, dtype=np.float64).reshape(-1, 3)
+    n = len(origins)
+    cfg = _Cfg(max_iterations, hit_threshold, max_distance, lipschitz)
+    hit = np.empty(n, dtype=np.uint8)
+    t = np.empty(n, dtype=np.float64)
+    iters = np.empty(n, dtype=np.int32)
+    fs = np.empty(n, dtype=np.float64)
+    rc = lib().rmo_march_rays(
+        scene_id, strategy_id, ctypes.byref(cfg), _dptr(origins), _dptr(dirs), n,
+        hit.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), _dptr(t),
+        iters.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _dptr(fs),
+    )
+    if rc:
+        raise ValueError(f"rmo_march_rays rc={rc}")
+    return hit, t, iters, fs

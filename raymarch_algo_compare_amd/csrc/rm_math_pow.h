@@ -1,0 +1,135 @@
+// rm_math_pow.h -- pow(x, y), bit-exact restatement of glibc 2.35 __pow_fma.
+//
+// Algorithm: glibc sysdeps/ieee754/dbl-64/e_pow.c (Szabolcs Nagy's pow from ARM
+// optimized-routines): log(x) as a double-double from a 128-entry table and a
+// degree-7 polynomial, y*log(x) as a double-double, exp() from a 128-entry 2^(i/128)
+// table and a degree-5 polynomial.  The x86-64 multiarch build compiles that file
+// with -mfma -mavx2 (so __FP_FAST_FMA paths are taken and gcc contracts a*b+c);
+// the operation order and the exact set of fused operations below were taken
+// from the machine code of the FMA variant, which is the one CPython reaches on
+// every FMA+AVX2 host (the build container and the GPU box alike).
+//
+// STATUS: EXACT for finite x >= 0 (including zero and subnormals), +inf, NaN, and
+// y with 2^-65 <= |y| < 2^63 whose result neither overflows nor underflows -- which
+// covers every call site of the path: `** 0.5` (vec3.py:46-47, primitives.py:24-32,49-50),
+// `** 2` (primitives.py:26) and `r ** 7.0`, `r ** 8.0` with r <= 4 (catalog.py:280,283).
+// Outside that domain (negative x, overflow/underflow of the result) the routine
+// falls back to the platform pow, which is not claimed exact.
+#pragma once
+
+#include "rm_libm_tables.h"
+
+namespace rm {
+
+RM_MATH_HD uint64_t rm_asuint64(double x) { return __builtin_bit_cast(uint64_t, x); }
+RM_MATH_HD double rm_asdouble(uint64_t u) { return __builtin_bit_cast(double, u); }
+
+// log(x) for positive normal-range bits `ix`, returned as hi + *tail.
+RM_MATH_HD double rm_pow_log_inline(uint64_t ix, double* tail)
+{
+    const double Ln2hi = rm_pow_log_head[0], Ln2lo = rm_pow_log_head[1];
+    const double A0 = rm_pow_log_head[2], A1 = rm_pow_log_head[3], A2 = rm_pow_log_head[4],
+                 A3 = rm_pow_log_head[5], A4 = rm_pow_log_head[6], A5 = rm_pow_log_head[7],
+                 A6 = rm_pow_log_head[8];
+    // x = 2^k z; where z is in range [OFF, 2*OFF) and exact.
+    uint64_t tmp = ix - 0x3fe6955500000000ull;
+    int i = (int)((tmp >> 45) & 127);
+    int k = (int)((int64_t)tmp >> 52);
+    uint64_t iz = ix - (tmp & 0xfff0000000000000ull);
+    double z = rm_asdouble(iz);
+    double kd = (double)k;
+    double invc = rm_pow_log_tab[4 * i + 0];
+    double logc = rm_pow_log_tab[4 * i + 2];
+    double logctail = rm_pow_log_tab[4 * i + 3];
+
+    double r = rm_fma(z, invc, -1.0);
+    // k*Ln2 + log(c) + r.
+    double t1 = rm_fma(kd, Ln2hi, logc);
+    double t2 = t1 + r;
+    double lo1 = rm_fma(kd, Ln2lo, logctail);
+    double lo2 = (t1 - t2) + r;
+    double ar = A0 * r;
+    double ar2 = r * ar;
+    double ar3 = r * ar2;
+    // k*Ln2 + log(c) + r + A[0]*r*r.
+    double hi = t2 + ar2;
+    double lo3 = rm_fma(ar, r, -ar2);
+    double lo4 = (t2 - hi) + ar2;
+    // p = log1p(r) - r - A[0]*r*r.
+    double p12 = rm_fma(r, A2, A1);
+    double p34 = rm_fma(r, A4, A3);
+    double p56 = rm_fma(r, A6, A5);
+    double q = rm_fma(p56, ar2, p34);
+    double pp = rm_fma(ar2, q, p12);
+    double lo = rm_fma(ar3, pp, ((lo1 + lo2) + lo3) + lo4);
+    double y = hi + lo;
+    *tail = (hi - y) + lo;
+    return y;
+}
+
+// platform pow for the unclaimed corner cases
+RM_MATH_HD double rm_pow_platform(double x, double y) { return ::pow(x, y); }
+
+RM_MATH_HD double rm_pow(double x, double y)
+{
+    uint64_t ix = rm_asuint64(x);
+    uint64_t iy = rm_asuint64(y);
+    uint32_t topx = (uint32_t)(ix >> 52);
+    uint32_t topy = (uint32_t)(iy >> 52) & 0x7ff;
+
+    if (__builtin_expect(topy - 0x3be > 0x7f, 0)) return rm_pow_platform(x, y);
+    if (__builtin_expect(topx - 1 > 0x7fd, 0)) {
+        // x is zero, subnormal, negative, inf or nan
+        if (x != x) return x + y;
+        if (ix >> 63) {
+            if (x == 0.0 && !(iy >> 63)) {
+                // pow(-0, y>0): -0 for odd integer y, +0 otherwise
+                double ay = rm_asdouble(iy);
+                bool odd = (ay == rm_trunc(ay)) && (rm_trunc(ay * 0.5) * 2.0 != ay) && ay < 0x1p53;
+                return odd ? -0.0 : 0.0;
+            }
+            return rm_pow_platform(x, y);
+        }
+        if (ix == 0) return (iy >> 63) ? rm_pow_platform(x, y) : 0.0;       // x*x in glibc
+        if (ix == 0x7ff0000000000000ull) return (iy >> 63) ? 0.0 : x;       // x*x / 1/(x*x)
+        // subnormal x: normalise (glibc: ix = asuint64(x * 0x1p52) & ~sign, ix -= 52 << 52)
+        ix = rm_asuint64(x * 0x1p52);
+        ix &= 0x7fffffffffffffffull;
+        ix -= 52ull << 52;
+    }
+
+    double lo;
+    double hi = rm_pow_log_inline(ix, &lo);
+    double ehi = y * hi;
+    double elo = rm_fma(y, lo, rm_fma(hi, y, -ehi));
+
+    // exp_inline(ehi, elo, 0)
+    uint32_t abstop = (uint32_t)(rm_asuint64(ehi) >> 52) & 0x7ff;
+    if (__builtin_expect(abstop - 0x3c9 >= 0x3f, 0)) {
+        if ((int32_t)(abstop - 0x3c9) < 0) return 1.0 + ehi;  // |y log x| < 2^-54
+        return rm_pow_platform(x, y);                         // |y log x| >= 512: unclaimed
+    }
+    const double InvLn2N = rm_exp_head[0], Shift = rm_exp_head[1], NegLn2hiN = rm_exp_head[2],
+                 NegLn2loN = rm_exp_head[3], C2 = rm_exp_head[4], C3 = rm_exp_head[5],
+                 C4 = rm_exp_head[6], C5 = rm_exp_head[7];
+    double kd = rm_fma(ehi, InvLn2N, Shift);
+    uint64_t ki = rm_asuint64(kd);
+    kd -= Shift;
+    double r = rm_fma(kd, NegLn2hiN, ehi);
+    r = rm_fma(kd, NegLn2loN, r);
+    r = elo + r;
+    uint32_t idx = 2 * (uint32_t)(ki & 127);
+    uint64_t top = ki << 45;
+    double tail = rm_asdouble(rm_exp_tab[idx]);
+    uint64_t sbits = rm_exp_tab[idx + 1] + top;
+    double r2 = r * r;
+    double a = rm_fma(r, C3, C2);
+    double b = rm_fma(r, C5, C4);
+    double c = rm_fma(a, r2, r + tail);
+    double r4 = r2 * r2;
+    double tmp = rm_fma(b, r4, c);
+    double scale = rm_asdouble(sbits);
+    return rm_fma(tmp, scale, scale);
+}
+
+}  // namespace rm
