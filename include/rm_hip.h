@@ -1,0 +1,152 @@
+/*
+ * rm_hip.h -- C ABI of librm_hip.so, the MI355X (gfx950) sphere-tracing engine.
+ *
+ * Drop-in boundary for ONE path of kylegrover/raymarch-algo-compare: the per-ray
+ * SDF sphere-tracing frame render.  Each entry point names the reference
+ * interface it replaces (paths relative to raymarching_benchmark/).  Plain
+ * pointers and sizes only; no C++ or torch types cross this boundary.  Nothing
+ * here falls back to a CPU implementation: every call fails with RM_E_NO_DEVICE /
+ * RM_E_HIP when no gfx950 device is usable.
+ *
+ * Ids: scene_id = index in get_all_scenes() (scenes/catalog.py:640-663), 0..19;
+ *      strategy_id = index in the STRATEGIES dict (strategies/__init__.py:16-28), 0..10.
+ * Threading: calls are synchronous unless stated; one in-flight call per device.
+ */
+#ifndef RM_HIP_H
+#define RM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RM_OK 0
+#define RM_E_BAD_SCENE (-1)
+#define RM_E_BAD_STRATEGY (-2)
+#define RM_E_BAD_DIMS (-3)
+#define RM_E_NO_DEVICE (-4)
+#define RM_E_HIP (-5)
+#define RM_E_BAD_ARG (-6)
+
+#define RM_NUM_SCENES 20
+#define RM_NUM_STRATEGIES 11
+#define RM_HIST_BINS 544 /* iterations histogram bins; counts >= RM_HIST_BINS-1 share the last bin */
+#define RM_MAX_TIMED 256
+
+/* MarchConfig (config.py:19-29) -- the three fields the CPU strategies read -- plus
+ * SegmentTracing.lipschitz as wired by run_once (main.py:58-61).
+ * full != 0 also produces MarchResult.final_sdf (costs the reference's tail evaluations). */
+typedef struct RmMarchConfig {
+    int32_t max_iterations; /* 512   */
+    int32_t full;
+    double hit_threshold;   /* 1e-4  */
+    double max_distance;    /* 100.0 */
+    double lipschitz;       /* 1.0   */
+} RmMarchConfig;
+
+/* One frame (or a row shard of it).  cam[14] = position, forward, right, up,
+ * half_width, half_height exactly as Camera.__init__ computes them (core/camera.py:11-33);
+ * rows [row0, row0+rows) of a width x height image are rendered, row 0 = top
+ * (core/types.py:90).  Output arrays hold rows*width elements, row-major from row0. */
+typedef struct RmFrameDesc {
+    int32_t scene_id;
+    int32_t strategy_id;
+    int32_t width, height;
+    int32_t row0, rows;
+    double cam[14];
+    RmMarchConfig march;
+    int32_t tile_rows;   /* 0 = default (4); 4 or 8: rows per 64-pixel-wide wave tile */
+    int32_t refill_min;  /* 0 = default; idle lanes required before a wave refills */
+    int32_t grid_waves;  /* 0 = default (fill the device); persistent wavefront count */
+    int32_t reserved;
+} RmFrameDesc;
+
+/* Frame reduce computed in-kernel (the integer part of RayMarchStats.compute, core/types.py:77-137). */
+typedef struct RmStats {
+    uint64_t total_rays;
+    uint64_t hit_count;
+    uint64_t sum_iters; /* sample_count */
+    int32_t iter_max;
+    int32_t iter_min;
+    uint64_t iter_hist[RM_HIST_BINS];
+} RmStats;
+
+/* in: warmup, repeats (<= RM_MAX_TIMED).  out: per-launch kernel milliseconds measured with
+ * hipEvents on the launch stream (cf. gpu/runner.py:139-165, main.py:152-153). */
+typedef struct RmTiming {
+    int32_t warmup;
+    int32_t repeats;
+    float ms_median, ms_mean, ms_min, ms_max;
+    float ms_each[RM_MAX_TIMED];
+} RmTiming;
+
+typedef struct RmDeviceInfo {
+    char name[128];
+    char arch[64];
+    int32_t device_id;
+    int32_t compute_units;
+    int32_t clock_mhz;
+    int32_t wavefront_size;
+    uint64_t total_mem_bytes;
+} RmDeviceInfo;
+
+/* Select the device and create the library's stream + workspace.  Must be called
+ * before anything else; idempotent for the same device. */
+int rm_init(int device_id);
+void rm_shutdown(void);
+/* Thread-local text of the last error on this thread (never NULL). */
+const char* rm_last_error(void);
+int rm_device_info(RmDeviceInfo* out);
+int rm_num_scenes(void);
+int rm_num_strategies(void);
+
+/* SDFScene.sdf (scenes/base.py:29-32) over n points; host pointers, xyz is n x 3. */
+int rm_sdf_eval(int scene_id, const double* xyz, size_t n, double* out);
+
+/* MarchStrategy.march (strategies/base.py:25-38) over n explicit rays; host pointers.
+ * Directions are normalised as Ray.__init__ does (core/ray.py:11-13). */
+int rm_march_rays(int scene_id, int strategy_id, const RmMarchConfig* cfg, const double* origins,
+                  const double* dirs, size_t n, uint8_t* hit, double* t, int32_t* iters, double* final_sdf);
+
+/* MetricsCollector.benchmark_strategy (metrics/collector.py:19-66): render the frame and
+ * copy the maps back.  Host pointers; depth/iters/hit are required (depth is fp32: t if hit
+ * else 0, core/types.py:93), the rest optional (NULL):
+ *   t_raw      fp64 termination parameter of every ray (MarchResult.t)
+ *   final_sdf  fp64 MarchResult.final_sdf (requires desc->march.full)
+ *   block_var  (rows/4) x (width/8) int64: 32*sum(x^2) - sum(x)^2 of the iteration counts of each
+ *              full 8x4 block (the population variance x 1024 behind warp_divergence_proxy,
+ *              core/types.py:125-133); requires row0 % 4 == 0
+ * With timing != NULL the kernel is launched warmup + repeats times and timed per launch. */
+int rm_render(const RmFrameDesc* desc, float* depth, int32_t* iters, uint8_t* hit, double* t_raw,
+              double* final_sdf, int64_t* block_var, RmStats* stats, RmTiming* timing);
+
+/* Same render, outputs left in device memory (caller-owned device pointers, e.g. torch
+ * tensors handed to RCCL afterwards).  Asynchronous on `stream` (a hipStream_t, NULL = the
+ * library stream).  d_stats: device buffer of rm_stats_device_bytes() bytes or NULL to use
+ * the library workspace; decode it with rm_read_stats after synchronising. */
+int rm_render_device(const RmFrameDesc* desc, void* d_depth, void* d_iters, void* d_hit, void* d_stats,
+                     void* stream);
+size_t rm_stats_device_bytes(void);
+int rm_read_stats(const void* d_stats, void* stream, RmStats* out);
+
+/* hipEvent-timed loop of rm_render_device on the library stream (device outputs stay resident). */
+int rm_bench_device(const RmFrameDesc* desc, void* d_depth, void* d_iters, void* d_hit, RmStats* stats,
+                    RmTiming* timing);
+
+/* Library-owned device frame buffers for callers without their own allocator. */
+int rm_alloc_frame(int32_t width, int32_t rows, void** d_depth, void** d_iters, void** d_hit);
+int rm_free_frame(void* d_depth, void* d_iters, void* d_hit);
+int rm_copy_frame_to_host(int32_t width, int32_t rows, const void* d_depth, const void* d_iters,
+                          const void* d_hit, float* depth, int32_t* iters, uint8_t* hit);
+
+/* Store-path probe: writes the 9 B/ray outputs with the render kernel's flush code and no
+ * marching, to measure the isolated HBM write bandwidth of the path. */
+int rm_bench_store_path(int32_t width, int32_t rows, void* d_depth, void* d_iters, void* d_hit,
+                        RmTiming* timing);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RM_HIP_H */

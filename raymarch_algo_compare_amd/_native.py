@@ -1,0 +1,232 @@
+"""ctypes binding of librm_hip.so (C ABI: include/rm_hip.h).
+
+Fails loudly: a missing library or a missing GPU raises RmError -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librm_hip.so")
+
+RM_NUM_SCENES = 20
+RM_NUM_STRATEGIES = 11
+RM_HIST_BINS = 544
+RM_MAX_TIMED = 256
+
+ERROR_NAMES = {0: "RM_OK", -1: "RM_E_BAD_SCENE", -2: "RM_E_BAD_STRATEGY", -3: "RM_E_BAD_DIMS",
+               -4: "RM_E_NO_DEVICE", -5: "RM_E_HIP", -6: "RM_E_BAD_ARG"}
+
+EXPORTS = [
+    "rm_init", "rm_shutdown", "rm_last_error", "rm_device_info", "rm_num_scenes", "rm_num_strategies",
+    "rm_sdf_eval", "rm_march_rays", "rm_render", "rm_render_device", "rm_stats_device_bytes",
+    "rm_read_stats", "rm_bench_device", "rm_alloc_frame", "rm_free_frame", "rm_copy_frame_to_host",
+    "rm_bench_store_path",
+]
+
+
+class RmError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"{ERROR_NAMES.get(code, code)}: {message}")
+        self.code = code
+
+
+class RmMarchConfig(ctypes.Structure):
+    _fields_ = [("max_iterations", ctypes.c_int32), ("full", ctypes.c_int32),
+                ("hit_threshold", ctypes.c_double), ("max_distance", ctypes.c_double),
+                ("lipschitz", ctypes.c_double)]
+
+
+class RmFrameDesc(ctypes.Structure):
+    _fields_ = [("scene_id", ctypes.c_int32), ("strategy_id", ctypes.c_int32),
+                ("width", ctypes.c_int32), ("height", ctypes.c_int32),
+                ("row0", ctypes.c_int32), ("rows", ctypes.c_int32),
+                ("cam", ctypes.c_double * 14), ("march", RmMarchConfig),
+                ("tile_rows", ctypes.c_int32), ("refill_min", ctypes.c_int32),
+                ("grid_waves", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class RmStats(ctypes.Structure):
+    _fields_ = [("total_rays", ctypes.c_uint64), ("hit_count", ctypes.c_uint64),
+                ("sum_iters", ctypes.c_uint64), ("iter_max", ctypes.c_int32), ("iter_min", ctypes.c_int32),
+                ("iter_hist", ctypes.c_uint64 * RM_HIST_BINS)]
+
+
+class RmTiming(ctypes.Structure):
+    _fields_ = [("warmup", ctypes.c_int32), ("repeats", ctypes.c_int32),
+                ("ms_median", ctypes.c_float), ("ms_mean", ctypes.c_float),
+                ("ms_min", ctypes.c_float), ("ms_max", ctypes.c_float),
+                ("ms_each", ctypes.c_float * RM_MAX_TIMED)]
+
+
+class RmDeviceInfo(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 128), ("arch", ctypes.c_char * 64),
+                ("device_id", ctypes.c_int32), ("compute_units", ctypes.c_int32),
+                ("clock_mhz", ctypes.c_int32), ("wavefront_size", ctypes.c_int32),
+                ("total_mem_bytes", ctypes.c_uint64)]
+
+
+_lib = None
+_lock = threading.Lock()
+_device = None
+
+
+def load() -> ctypes.CDLL:
+    """dlopen librm_hip.so and declare the prototypes (no GPU call is made)."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RmError(-4, f"{LIB_PATH} is missing: build it with "
+                              f"`make -C {os.path.join(_HERE, 'csrc')} -j8` (or __graft_entry__.build())")
+        L = ctypes.CDLL(LIB_PATH)
+        vp, dp = ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)
+        L.rm_init.argtypes = [ctypes.c_int]
+        L.rm_shutdown.restype = None
+        L.rm_last_error.restype = ctypes.c_char_p
+        L.rm_device_info.argtypes = [ctypes.POINTER(RmDeviceInfo)]
+        L.rm_sdf_eval.argtypes = [ctypes.c_int, dp, ctypes.c_size_t, dp]
+        L.rm_march_rays.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(RmMarchConfig), dp, dp,
+                                    ctypes.c_size_t, vp, dp, vp, dp]
+        L.rm_render.argtypes = [ctypes.POINTER(RmFrameDesc), vp, vp, vp, vp, vp, vp,
+                                ctypes.POINTER(RmStats), ctypes.POINTER(RmTiming)]
+        L.rm_render_device.argtypes = [ctypes.POINTER(RmFrameDesc), vp, vp, vp, vp, vp]
+        L.rm_stats_device_bytes.restype = ctypes.c_size_t
+        L.rm_read_stats.argtypes = [vp, vp, ctypes.POINTER(RmStats)]
+        L.rm_bench_device.argtypes = [ctypes.POINTER(RmFrameDesc), vp, vp, vp, ctypes.POINTER(RmStats),
+                                      ctypes.POINTER(RmTiming)]
+        L.rm_alloc_frame.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                     ctypes.POINTER(vp)]
+        L.rm_free_frame.argtypes = [vp, vp, vp]
+        L.rm_copy_frame_to_host.argtypes = [ctypes.c_int32, ctypes.c_int32, vp, vp, vp, vp, vp, vp]
+        L.rm_bench_store_path.argtypes = [ctypes.c_int32, ctypes.c_int32, vp, vp, vp, ctypes.POINTER(RmTiming)]
+        for name in EXPORTS:
+            if name not in ("rm_shutdown", "rm_last_error", "rm_stats_device_bytes"):
+                getattr(L, name).restype = ctypes.c_int
+        _lib = L
+        return L
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise RmError(rc, load().rm_last_error().decode("utf-8", "replace"))
+
+
+def init(device_id: int | None = None) -> ctypes.CDLL:
+    """Bind the library to a GPU (default: $LOCAL_RANK or 0).  Raises RmError without one."""
+    global _device
+    L = load()
+    if device_id is None:
+        device_id = _device if _device is not None else int(os.environ.get("LOCAL_RANK", "0"))
+    if _device == device_id:
+        return L
+    if _device is not None:
+        L.rm_shutdown()
+        _device = None
+    check(L.rm_init(int(device_id)))
+    _device = device_id
+    return L
+
+
+def device_info() -> dict:
+    L = init()
+    info = RmDeviceInfo()
+    check(L.rm_device_info(ctypes.byref(info)))
+    return {"name": info.name.decode(), "arch": info.arch.decode(), "device_id": info.device_id,
+            "compute_units": info.compute_units, "clock_mhz": info.clock_mhz,
+            "wavefront_size": info.wavefront_size, "total_mem_bytes": int(info.total_mem_bytes)}
+
+
+def make_desc(scene_id, strategy_id, cam14, width, height, row0=0, rows=None, max_iterations=512,
+              hit_threshold=1e-4, max_distance=100.0, lipschitz=1.0, full=False, tile_rows=0, refill_min=0,
+              grid_waves=0) -> RmFrameDesc:
+    d = RmFrameDesc()
+    d.scene_id, d.strategy_id = int(scene_id), int(strategy_id)
+    d.width, d.height = int(width), int(height)
+    d.row0 = int(row0)
+    d.rows = int(height - row0 if rows is None else rows)
+    cam14 = np.asarray(cam14, dtype=np.float64).ravel()
+    if cam14.size != 14:
+        raise ValueError("cam14 must hold 14 doubles")
+    for i in range(14):
+        d.cam[i] = float(cam14[i])
+    d.march.max_iterations = int(max_iterations)
+    d.march.full = 1 if full else 0
+    d.march.hit_threshold = float(hit_threshold)
+    d.march.max_distance = float(max_distance)
+    d.march.lipschitz = float(lipschitz)
+    d.tile_rows, d.refill_min, d.grid_waves = int(tile_rows), int(refill_min), int(grid_waves)
+    return d
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def timing_dict(t: RmTiming) -> dict:
+    return {"warmup": t.warmup, "repeats": t.repeats, "ms_median": float(t.ms_median),
+            "ms_mean": float(t.ms_mean), "ms_min": float(t.ms_min), "ms_max": float(t.ms_max),
+            "ms_each": [float(t.ms_each[i]) for i in range(t.repeats)]}
+
+
+def stats_dict(s: RmStats) -> dict:
+    return {"total_rays": int(s.total_rays), "hit_count": int(s.hit_count), "sum_iters": int(s.sum_iters),
+            "iter_max": int(s.iter_max), "iter_min": int(s.iter_min),
+            "iter_hist": np.ctypeslib.as_array(s.iter_hist).astype(np.int64).copy()}
+
+
+def render(desc: RmFrameDesc, want_t_raw=False, want_final_sdf=False, want_block_var=False, warmup=0,
+           repeats=0) -> dict:
+    """rm_render into fresh NumPy arrays.  Returns depth (f32), iters (i32), hit (u8), optional
+    t_raw / final_sdf (f64) / block_var (i64), stats (dict) and timing (dict or None)."""
+    L = init()
+    rows, W = desc.rows, desc.width
+    out = {"depth": np.empty((rows, W), np.float32), "iters": np.empty((rows, W), np.int32),
+           "hit": np.empty((rows, W), np.uint8), "t_raw": None, "final_sdf": None, "block_var": None}
+    if want_t_raw:
+        out["t_raw"] = np.empty((rows, W), np.float64)
+    if want_final_sdf:
+        out["final_sdf"] = np.empty((rows, W), np.float64)
+    if want_block_var:
+        out["block_var"] = np.empty((rows // 4, W // 8), np.int64)
+    st = RmStats()
+    tm = None
+    if repeats > 0:
+        tm = RmTiming()
+        tm.warmup, tm.repeats = int(warmup), int(repeats)
+    check(L.rm_render(ctypes.byref(desc), _ptr(out["depth"]), _ptr(out["iters"]), _ptr(out["hit"]),
+                      _ptr(out["t_raw"]), _ptr(out["final_sdf"]), _ptr(out["block_var"]), ctypes.byref(st),
+                      ctypes.byref(tm) if tm is not None else None))
+    out["stats"] = stats_dict(st)
+    out["timing"] = timing_dict(tm) if tm is not None else None
+    return out
+
+
+def sdf_eval(scene_id: int, pts) -> np.ndarray:
+    L = init()
+    pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
+    out = np.empty(len(pts), np.float64)
+    dp = ctypes.POINTER(ctypes.c_double)
+    check(L.rm_sdf_eval(int(scene_id), pts.ctypes.data_as(dp), len(pts), out.ctypes.data_as(dp)))
+    return out
+
+
+def march_rays(scene_id, strategy_id, origins, dirs, max_iterations=512, hit_threshold=1e-4, max_distance=100.0,
+               lipschitz=1.0):
+    L = init()
+    origins = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
+    dirs = np.ascontiguousarray(dirs, dtype=np.float64).reshape(-1, 3)
+    n = len(origins)
+    cfg = RmMarchConfig(int(max_iterations), 1, float(hit_threshold), float(max_distance), float(lipschitz))
+    hit, t = np.empty(n, np.uint8), np.empty(n, np.float64)
+    iters, fs = np.empty(n, np.int32), np.empty(n, np.float64)
+    dp = ctypes.POINTER(ctypes.c_double)
+    check(L.rm_march_rays(int(scene_id), int(strategy_id), ctypes.byref(cfg), origins.ctypes.data_as(dp),
+                          dirs.ctypes.data_as(dp), n, _ptr(hit), t.ctypes.data_as(dp), _ptr(iters),
+                          fs.ctypes.data_as(dp)))
+    return hit, t, iters, fs

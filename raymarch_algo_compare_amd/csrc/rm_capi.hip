@@ -1,0 +1,506 @@
+// rm_capi.hip -- host side of librm_hip.so: the C ABI declared in include/rm_hip.h.
+//
+// Owns the device selection, one HIP stream, a grow-only device workspace and the
+// (scene, strategy) -> kernel dispatch.  No CPU implementation of the path exists in
+// this library: without a usable gfx950 device every entry point returns an error.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "../../include/rm_hip.h"
+#include "rm_kernels.h"
+
+static_assert(RM_HIST_BINS == rm::kHistBins, "histogram size mismatch between ABI and kernels");
+static_assert(RM_NUM_SCENES == 20 && RM_NUM_STRATEGIES == 11, "registry size");
+
+namespace rm {
+#define RM_X(id, S) const SceneLaunchers* scene_launchers_##id();
+RM_SCENE_LIST(RM_X)
+#undef RM_X
+static const SceneLaunchers* scene(int id)
+{
+    switch (id) {
+#define RM_X(id, S) case id: return scene_launchers_##id();
+        RM_SCENE_LIST(RM_X)
+#undef RM_X
+    }
+    return nullptr;
+}
+}  // namespace rm
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(RM_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct Buf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return RM_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return fail(RM_E_HIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        cap = bytes;
+        return RM_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+    }
+};
+
+struct State {
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop;
+    Buf stats, depth, iters, hit, traw, fs, bvar, in0, in1, out0, out1, out2, out3;
+    hipEvent_t ev[2 * RM_MAX_TIMED];
+    bool events = false;
+} g;
+
+std::mutex g_mu;
+
+constexpr size_t kStatsBytes = sizeof(unsigned long long) * rm::kStatsWords;
+
+int check_ready()
+{
+    if (!g.ready) return fail(RM_E_NO_DEVICE, "rm_init() has not succeeded: no gfx950 device bound");
+    return RM_OK;
+}
+
+int check_desc(const RmFrameDesc* d)
+{
+    if (!d) return fail(RM_E_BAD_ARG, "desc is NULL");
+    if (d->scene_id < 0 || d->scene_id >= RM_NUM_SCENES) return fail(RM_E_BAD_SCENE, "scene_id %d out of range", d->scene_id);
+    if (d->strategy_id < 0 || d->strategy_id >= RM_NUM_STRATEGIES)
+        return fail(RM_E_BAD_STRATEGY, "strategy_id %d out of range", d->strategy_id);
+    if (d->width <= 0 || d->height <= 0 || d->row0 < 0 || d->rows < 0 || d->row0 + d->rows > d->height)
+        return fail(RM_E_BAD_DIMS, "bad frame slice: %dx%d rows [%d,%d)", d->width, d->height, d->row0, d->row0 + d->rows);
+    if ((long long)d->width * d->height > (1ll << 31) - 1) return fail(RM_E_BAD_DIMS, "frame too large");
+    if (d->tile_rows != 0 && d->tile_rows != 4 && d->tile_rows != 8) return fail(RM_E_BAD_ARG, "tile_rows must be 0, 4 or 8");
+    return RM_OK;
+}
+
+rm::MarchCfg to_cfg(const RmMarchConfig& m)
+{
+    rm::MarchCfg c;
+    c.hit_threshold = m.hit_threshold;
+    c.max_distance = m.max_distance;
+    c.lipschitz = m.lipschitz;
+    c.max_iterations = m.max_iterations;
+    c.full = m.full ? 1 : 0;
+    return c;
+}
+
+// Fill kernel arguments + choose the persistent grid.
+int make_args(const RmFrameDesc* d, float* depth, int32_t* iters, uint8_t* hit, double* traw, double* fs,
+              long long* bvar, unsigned long long* stats, rm::KernelArgs* a, int* tile_h, int* grid)
+{
+    const int th = d->tile_rows ? d->tile_rows : 4;
+    memset(a, 0, sizeof *a);
+    for (int i = 0; i < 14; ++i) a->cam.v[i] = d->cam[i];
+    a->cfg = to_cfg(d->march);
+    a->width = d->width; a->height = d->height; a->row0 = d->row0; a->rows = d->rows;
+    a->tiles_x = (d->width + rm::kTileW - 1) / rm::kTileW;
+    a->tiles_y = (d->rows + th - 1) / th;
+    a->refill_min = d->refill_min > 0 ? d->refill_min : 24;
+    a->hist_bins = rm::kHistBins;
+    a->depth = depth; a->iters = iters; a->hit = hit; a->t_raw = traw; a->final_sdf = fs;
+    a->block_var = bvar; a->stats = stats;
+    *tile_h = th;
+    const long long ntiles = (long long)a->tiles_x * a->tiles_y;
+    int waves = d->grid_waves;
+    if (waves <= 0) {
+        int per_cu = 0;
+        hipError_t e = rm::scene(d->scene_id)->occupancy(d->strategy_id, th, &per_cu);
+        if (e != hipSuccess || per_cu <= 0) per_cu = 8;
+        waves = g.prop.multiProcessorCount * per_cu;
+    }
+    *grid = (int)std::max<long long>(1, std::min<long long>(waves, ntiles));
+    return RM_OK;
+}
+
+int launch(const RmFrameDesc* d, const rm::KernelArgs& a, int tile_h, int grid, hipStream_t s)
+{
+    HIP_TRY(hipMemsetAsync(a.stats, 0, kStatsBytes, s));
+    if (d->rows == 0) return RM_OK;
+    HIP_TRY(rm::scene(d->scene_id)->render(d->strategy_id, tile_h, a, grid, s));
+    return RM_OK;
+}
+
+void decode_stats(const unsigned long long* w, RmStats* out)
+{
+    out->hit_count = w[1];
+    out->sum_iters = w[2];
+    out->iter_max = (int32_t)w[3];
+    out->total_rays = w[5];
+    out->iter_min = w[5] ? (int32_t)(0x7fffffffull - w[4]) : 0;
+    for (int b = 0; b < RM_HIST_BINS; ++b) out->iter_hist[b] = w[8 + b];
+}
+
+void summarise(RmTiming* t)
+{
+    const int n = t->repeats;
+    if (n <= 0) { t->ms_median = t->ms_mean = t->ms_min = t->ms_max = 0.f; return; }
+    std::vector<float> v(t->ms_each, t->ms_each + n);
+    std::sort(v.begin(), v.end());
+    t->ms_min = v.front(); t->ms_max = v.back();
+    t->ms_median = (n & 1) ? v[n / 2] : 0.5f * (v[n / 2 - 1] + v[n / 2]);
+    double sum = 0; for (float x : v) sum += x;
+    t->ms_mean = (float)(sum / n);
+}
+
+int ensure_events()
+{
+    if (g.events) return RM_OK;
+    for (auto& e : g.ev) HIP_TRY(hipEventCreate(&e));
+    g.events = true;
+    return RM_OK;
+}
+
+// Launch warmup + repeats times; each timed launch bracketed by events on the launch stream.
+int timed_launches(const RmFrameDesc* d, const rm::KernelArgs& a, int tile_h, int grid, RmTiming* t)
+{
+    if (t->repeats < 1 || t->repeats > RM_MAX_TIMED || t->warmup < 0)
+        return fail(RM_E_BAD_ARG, "timing: repeats must be 1..%d, warmup >= 0", RM_MAX_TIMED);
+    int rc = ensure_events();
+    if (rc) return rc;
+    for (int i = 0; i < t->warmup; ++i)
+        if ((rc = launch(d, a, tile_h, grid, g.stream))) return rc;
+    for (int i = 0; i < t->repeats; ++i) {
+        // the stats/tile-counter reset is part of a frame; the events bracket the kernel only
+        HIP_TRY(hipMemsetAsync(a.stats, 0, kStatsBytes, g.stream));
+        HIP_TRY(hipEventRecord(g.ev[2 * i], g.stream));
+        if (d->rows) HIP_TRY(rm::scene(d->scene_id)->render(d->strategy_id, tile_h, a, grid, g.stream));
+        HIP_TRY(hipEventRecord(g.ev[2 * i + 1], g.stream));
+    }
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    for (int i = 0; i < t->repeats; ++i) HIP_TRY(hipEventElapsedTime(&t->ms_each[i], g.ev[2 * i], g.ev[2 * i + 1]));
+    summarise(t);
+    return RM_OK;
+}
+
+// ---- store-path probe: the flush of render_kernel without the march --------------------
+__global__ __launch_bounds__(64) void store_path_kernel(float* depth, int32_t* iters, uint8_t* hit, int width,
+                                                        int rows, int tiles_x, int ntiles)
+{
+    constexpr int TILE_H = 4;
+    __shared__ float s_depth[64 * TILE_H];
+    __shared__ int32_t s_iters[64 * TILE_H];
+    __shared__ uint8_t s_hit[64 * TILE_H];
+    const int lane = threadIdx.x;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int x0 = (tile % tiles_x) * 64, y0 = (tile / tiles_x) * TILE_H;
+        for (int r = 0; r < TILE_H; ++r) {
+            s_depth[r * 64 + lane] = (float)(tile + r);
+            s_iters[r * 64 + lane] = tile ^ lane;
+            s_hit[r * 64 + lane] = (uint8_t)((tile + lane) & 1);
+        }
+        __syncthreads();
+        const int gx = x0 + lane;
+        for (int r = 0; r < TILE_H; ++r)
+            if (gx < width && y0 + r < rows) {
+                const size_t gi = (size_t)(y0 + r) * width + gx;
+                depth[gi] = s_depth[r * 64 + lane];
+                iters[gi] = s_iters[r * 64 + lane];
+                hit[gi] = s_hit[r * 64 + lane];
+            }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rm_last_error(void) { return g_err; }
+int rm_num_scenes(void) { return RM_NUM_SCENES; }
+int rm_num_strategies(void) { return RM_NUM_STRATEGIES; }
+size_t rm_stats_device_bytes(void) { return kStatsBytes; }
+
+int rm_init(int device_id)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g.ready && g.device == device_id) return RM_OK;
+    if (g.ready) return fail(RM_E_BAD_ARG, "already initialised on device %d; call rm_shutdown() first", g.device);
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(RM_E_NO_DEVICE, "no HIP device available (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) return fail(RM_E_NO_DEVICE, "device %d out of range (have %d)", device_id, n);
+    HIP_TRY(hipSetDevice(device_id));
+    HIP_TRY(hipGetDeviceProperties(&g.prop, device_id));
+    if (strncmp(g.prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RM_E_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device_id, g.prop.gcnArchName);
+    HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    int rc = g.stats.ensure(kStatsBytes);
+    if (rc) return rc;
+    g.device = device_id;
+    g.ready = true;
+    return RM_OK;
+}
+
+void rm_shutdown(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g.ready) return;
+    (void)hipSetDevice(g.device);
+    (void)hipStreamSynchronize(g.stream);
+    for (Buf* b : { &g.stats, &g.depth, &g.iters, &g.hit, &g.traw, &g.fs, &g.bvar, &g.in0, &g.in1, &g.out0, &g.out1,
+                    &g.out2, &g.out3 })
+        b->release();
+    if (g.events) for (auto& e : g.ev) (void)hipEventDestroy(e);
+    g.events = false;
+    (void)hipStreamDestroy(g.stream);
+    g.stream = nullptr;
+    g.ready = false;
+    g.device = -1;
+}
+
+int rm_device_info(RmDeviceInfo* out)
+{
+    int rc = check_ready();
+    if (rc) return rc;
+    if (!out) return fail(RM_E_BAD_ARG, "out is NULL");
+    memset(out, 0, sizeof *out);
+    snprintf(out->name, sizeof out->name, "%s", g.prop.name);
+    snprintf(out->arch, sizeof out->arch, "%s", g.prop.gcnArchName);
+    out->device_id = g.device;
+    out->compute_units = g.prop.multiProcessorCount;
+    out->clock_mhz = g.prop.clockRate / 1000;
+    out->wavefront_size = g.prop.warpSize;
+    out->total_mem_bytes = g.prop.totalGlobalMem;
+    return RM_OK;
+}
+
+int rm_sdf_eval(int scene_id, const double* xyz, size_t n, double* out)
+{
+    int rc = check_ready();
+    if (rc) return rc;
+    if (scene_id < 0 || scene_id >= RM_NUM_SCENES) return fail(RM_E_BAD_SCENE, "scene_id %d out of range", scene_id);
+    if (n == 0) return RM_OK;
+    if (!xyz || !out) return fail(RM_E_BAD_ARG, "NULL buffer");
+    std::lock_guard<std::mutex> lk(g_mu);
+    HIP_TRY(hipSetDevice(g.device));
+    if ((rc = g.in0.ensure(n * 24)) || (rc = g.out0.ensure(n * 8))) return rc;
+    HIP_TRY(hipMemcpyAsync(g.in0.p, xyz, n * 24, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(rm::scene(scene_id)->sdf_eval((const double*)g.in0.p, n, (double*)g.out0.p, g.stream));
+    HIP_TRY(hipMemcpyAsync(out, g.out0.p, n * 8, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return RM_OK;
+}
+
+int rm_march_rays(int scene_id, int strategy_id, const RmMarchConfig* cfg, const double* origins, const double* dirs,
+                  size_t n, uint8_t* hit, double* t, int32_t* iters, double* final_sdf)
+{
+    int rc = check_ready();
+    if (rc) return rc;
+    if (scene_id < 0 || scene_id >= RM_NUM_SCENES) return fail(RM_E_BAD_SCENE, "scene_id %d out of range", scene_id);
+    if (strategy_id < 0 || strategy_id >= RM_NUM_STRATEGIES)
+        return fail(RM_E_BAD_STRATEGY, "strategy_id %d out of range", strategy_id);
+    if (!cfg) return fail(RM_E_BAD_ARG, "cfg is NULL");
+    if (n == 0) return RM_OK;
+    if (!origins || !dirs || !hit || !t || !iters || !final_sdf) return fail(RM_E_BAD_ARG, "NULL buffer");
+    std::lock_guard<std::mutex> lk(g_mu);
+    HIP_TRY(hipSetDevice(g.device));
+    if ((rc = g.in0.ensure(n * 24)) || (rc = g.in1.ensure(n * 24)) || (rc = g.out0.ensure(n)) ||
+        (rc = g.out1.ensure(n * 8)) || (rc = g.out2.ensure(n * 4)) || (rc = g.out3.ensure(n * 8)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(g.in0.p, origins, n * 24, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(g.in1.p, dirs, n * 24, hipMemcpyHostToDevice, g.stream));
+    rm::MarchCfg c = to_cfg(*cfg);
+    c.full = 1;   // per-ray API always returns final_sdf, like MarchResult
+    HIP_TRY(rm::scene(scene_id)->march_rays(strategy_id, c, (const double*)g.in0.p, (const double*)g.in1.p, n,
+                                               (uint8_t*)g.out0.p, (double*)g.out1.p, (int32_t*)g.out2.p,
+                                               (double*)g.out3.p, g.stream));
+    HIP_TRY(hipMemcpyAsync(hit, g.out0.p, n, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipMemcpyAsync(t, g.out1.p, n * 8, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipMemcpyAsync(iters, g.out2.p, n * 4, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipMemcpyAsync(final_sdf, g.out3.p, n * 8, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return RM_OK;
+}
+
+int rm_render(const RmFrameDesc* d, float* depth, int32_t* iters, uint8_t* hit, double* t_raw, double* final_sdf,
+              int64_t* block_var, RmStats* stats, RmTiming* timing)
+{
+    int rc = check_ready();
+    if (rc) return rc;
+    if ((rc = check_desc(d))) return rc;
+    if (!depth || !iters || !hit) return fail(RM_E_BAD_ARG, "depth, iters and hit are required");
+    if (final_sdf && !d->march.full) return fail(RM_E_BAD_ARG, "final_sdf requires march.full = 1");
+    if (block_var && (d->row0 % 4) != 0) return fail(RM_E_BAD_ARG, "block_var requires row0 %% 4 == 0");
+    std::lock_guard<std::mutex> lk(g_mu);
+    HIP_TRY(hipSetDevice(g.device));
+    const size_t n = (size_t)d->rows * (size_t)d->width;
+    const size_t nblk = (size_t)(d->rows / 4) * (size_t)(d->width / 8);
+    if ((rc = g.depth.ensure(n * 4 + 16)) || (rc = g.iters.ensure(n * 4 + 16)) || (rc = g.hit.ensure(n + 16))) return rc;
+    if (t_raw && (rc = g.traw.ensure(n * 8 + 16))) return rc;
+    if (final_sdf && (rc = g.fs.ensure(n * 8 + 16))) return rc;
+    if (block_var && (rc = g.bvar.ensure(nblk * 8 + 16))) return rc;
+    rm::KernelArgs a;
+    int tile_h = 0, grid = 0;
+    if ((rc = make_args(d, (float*)g.depth.p, (int32_t*)g.iters.p, (uint8_t*)g.hit.p, t_raw ? (double*)g.traw.p : nullptr,
+                        final_sdf ? (double*)g.fs.p : nullptr, block_var ? (long long*)g.bvar.p : nullptr,
+                        (unsigned long long*)g.stats.p, &a, &tile_h, &grid)))
+        return rc;
+    if (timing) {
+        if ((rc = timed_launches(d, a, tile_h, grid, timing))) return rc;
+    } else {
+        if ((rc = launch(d, a, tile_h, grid, g.stream))) return rc;
+    }
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(depth, g.depth.p, n * 4, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipMemcpyAsync(iters, g.iters.p, n * 4, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipMemcpyAsync(hit, g.hit.p, n, hipMemcpyDeviceToHost, g.stream));
+        if (t_raw) HIP_TRY(hipMemcpyAsync(t_raw, g.traw.p, n * 8, hipMemcpyDeviceToHost, g.stream));
+        if (final_sdf) HIP_TRY(hipMemcpyAsync(final_sdf, g.fs.p, n * 8, hipMemcpyDeviceToHost, g.stream));
+        if (block_var && nblk) HIP_TRY(hipMemcpyAsync(block_var, g.bvar.p, nblk * 8, hipMemcpyDeviceToHost, g.stream));
+    }
+    unsigned long long w[rm::kStatsWords];
+    HIP_TRY(hipMemcpyAsync(w, g.stats.p, kStatsBytes, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    if (stats) decode_stats(w, stats);
+    return RM_OK;
+}
+
+int rm_render_device(const RmFrameDesc* d, void* d_depth, void* d_iters, void* d_hit, void* d_stats, void* stream)
+{
+    int rc = check_ready();
+    if (rc) return rc;
+    if ((rc = check_desc(d))) return rc;
+    if (!d_depth || !d_iters || !d_hit) return fail(RM_E_BAD_ARG, "device output pointers are required");
+    HIP_TRY(hipSetDevice(g.device));
+    rm::KernelArgs a;
+    int tile_h = 0, grid = 0;
+    if ((rc = make_args(d, (float*)d_depth, (int32_t*)d_iters, (uint8_t*)d_hit, nullptr, nullptr, nullptr,
+                        (unsigned long long*)(d_stats ? d_stats : g.stats.p), &a, &tile_h, &grid)))
+        return rc;
+    return launch(d, a, tile_h, grid, stream ? (hipStream_t)stream : g.stream);
+}
+
+int rm_read_stats(const void* d_stats, void* stream, RmStats* out)
+{
+    int rc = check_ready();
+    if (rc) return rc;
+    if (!out) return fail(RM_E_BAD_ARG, "out is NULL");
+    hipStream_t s = stream ? (hipStream_t)stream : g.stream;
+    unsigned long long w[rm::kStatsWords];
+    HIP_TRY(hipMemcpyAsync(w, d_stats ? d_stats : g.stats.p, kStatsBytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    decode_stats(w, out);
+    return RM_OK;
+}
+
+int rm_bench_device(const RmFrameDesc* d, void* d_depth, void* d_iters, void* d_hit, RmStats* stats, RmTiming* timing)
+{
+    int rc = check_ready();
+    if (rc) return rc;
+    if ((rc = check_desc(d))) return rc;
+    if (!d_depth || !d_iters || !d_hit || !timing) return fail(RM_E_BAD_ARG, "device outputs and timing are required");
+    std::lock_guard<std::mutex> lk(g_mu);
+    HIP_TRY(hipSetDevice(g.device));
+    rm::KernelArgs a;
+    int tile_h = 0, grid = 0;
+    if ((rc = make_args(d, (float*)d_depth, (int32_t*)d_iters, (uint8_t*)d_hit, nullptr, nullptr, nullptr,
+                        (unsigned long long*)g.stats.p, &a, &tile_h, &grid)))
+        return rc;
+    if ((rc = timed_launches(d, a, tile_h, grid, timing))) return rc;
+    if (stats) {
+        unsigned long long w[rm::kStatsWords];
+        HIP_TRY(hipMemcpy(w, g.stats.p, kStatsBytes, hipMemcpyDeviceToHost));
+        decode_stats(w, stats);
+    }
+    return RM_OK;
+}
+
+int rm_alloc_frame(int32_t width, int32_t rows, void** d_depth, void** d_iters, void** d_hit)
+{
+    int rc = check_ready();
+    if (rc) return rc;
+    if (width <= 0 || rows <= 0 || !d_depth || !d_iters || !d_hit) return fail(RM_E_BAD_ARG, "bad arguments");
+    HIP_TRY(hipSetDevice(g.device));
+    const size_t n = (size_t)width * rows;
+    HIP_TRY(hipMalloc(d_depth, n * 4));
+    HIP_TRY(hipMalloc(d_iters, n * 4));
+    HIP_TRY(hipMalloc(d_hit, n));
+    return RM_OK;
+}
+
+int rm_free_frame(void* d_depth, void* d_iters, void* d_hit)
+{
+    int rc = check_ready();
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(g.device));
+    if (d_depth) HIP_TRY(hipFree(d_depth));
+    if (d_iters) HIP_TRY(hipFree(d_iters));
+    if (d_hit) HIP_TRY(hipFree(d_hit));
+    return RM_OK;
+}
+
+int rm_copy_frame_to_host(int32_t width, int32_t rows, const void* d_depth, const void* d_iters, const void* d_hit,
+                          float* depth, int32_t* iters, uint8_t* hit)
+{
+    int rc = check_ready();
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(g.device));
+    const size_t n = (size_t)width * rows;
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    if (depth) HIP_TRY(hipMemcpy(depth, d_depth, n * 4, hipMemcpyDeviceToHost));
+    if (iters) HIP_TRY(hipMemcpy(iters, d_iters, n * 4, hipMemcpyDeviceToHost));
+    if (hit) HIP_TRY(hipMemcpy(hit, d_hit, n, hipMemcpyDeviceToHost));
+    return RM_OK;
+}
+
+int rm_bench_store_path(int32_t width, int32_t rows, void* d_depth, void* d_iters, void* d_hit, RmTiming* t)
+{
+    int rc = check_ready();
+    if (rc) return rc;
+    if (width <= 0 || rows <= 0 || !d_depth || !d_iters || !d_hit || !t) return fail(RM_E_BAD_ARG, "bad arguments");
+    if (t->repeats < 1 || t->repeats > RM_MAX_TIMED || t->warmup < 0) return fail(RM_E_BAD_ARG, "bad timing request");
+    std::lock_guard<std::mutex> lk(g_mu);
+    HIP_TRY(hipSetDevice(g.device));
+    if ((rc = ensure_events())) return rc;
+    const int tiles_x = (width + 63) / 64, tiles_y = (rows + 3) / 4;
+    const int ntiles = tiles_x * tiles_y;
+    const int grid = std::min(ntiles, g.prop.multiProcessorCount * 32);
+    for (int i = 0; i < t->warmup + t->repeats; ++i) {
+        const int k = i - t->warmup;
+        if (k >= 0) HIP_TRY(hipEventRecord(g.ev[2 * k], g.stream));
+        hipLaunchKernelGGL(store_path_kernel, dim3(grid), dim3(64), 0, g.stream, (float*)d_depth, (int32_t*)d_iters,
+                           (uint8_t*)d_hit, width, rows, tiles_x, ntiles);
+        HIP_TRY(hipGetLastError());
+        if (k >= 0) HIP_TRY(hipEventRecord(g.ev[2 * k + 1], g.stream));
+    }
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    for (int i = 0; i < t->repeats; ++i) HIP_TRY(hipEventElapsedTime(&t->ms_each[i], g.ev[2 * i], g.ev[2 * i + 1]));
+    summarise(t);
+    return RM_OK;
+}
+
+}  // extern "C"

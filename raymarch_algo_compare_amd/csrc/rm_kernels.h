@@ -1,0 +1,250 @@
+// rm_kernels.h -- gfx950 kernels of the sphere-tracing frame render.
+//
+// One kernel instantiation per (scene, strategy): camera ray generation
+// (camera.py:35-41), the scene SDF (catalog.py) and the strategy state machine
+// (strategies/*.py) are all inlined; this replaces the reference's frame loop
+// MetricsCollector.benchmark_strategy (metrics/collector.py:40-44).
+//
+// Execution shape (CDNA4, 64-lane wavefronts; VALU/fp64 bound, not HBM bound):
+//  * one wavefront per workgroup, persistent: each wave pulls 64 x TILE_H pixel
+//    tiles from a global atomic counter until none are left (every wave reaches
+//    the exit test, the grid always drains);
+//  * one ray per lane, all per-ray state in VGPRs.  A lane that finishes its ray
+//    takes the next unassigned pixel of the wave's tile ("lane refill"), so a
+//    512-step straggler ray does not idle the other 63 lanes; refills are batched
+//    (REFILL_MIN idle lanes) so ray set-up code runs with a reasonably full EXEC;
+//  * results are staged per tile in LDS and flushed as full-row 256-byte (depth,
+//    iterations) / 64-byte (hit) contiguous stores: the only HBM traffic of the
+//    path, 9 bytes per ray (4 fp32 depth + 4 int32 iterations + 1 uint8 hit);
+//  * frame statistics ride along: per-wave register accumulators (hit count,
+//    iteration sum/max/min), a per-wave LDS iteration histogram flushed once at
+//    kernel exit, and the reference's 8x4-block "warp divergence" variance
+//    numerators (core/types.py:125-133) reduced in-wave with DPP shuffles.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rm_camera.h"
+#include "rm_scenes.h"
+#include "rm_strategies.h"
+
+namespace rm {
+
+constexpr int kTileW = 64;          // one tile row == one wavefront-wide store
+constexpr int kHistBins = 544;      // iterations <= max_iterations + 9 (Segment 521, RevAA 520) for 512
+constexpr int kStatsWords = 8 + kHistBins;  // u64 words, layout below
+
+// device-side stats block (u64 words):
+//  [0] tile counter   [1] hit_count   [2] sum_iters   [3] iter_max   [4] 0x7fffffff - iter_min
+//  [5] rays written   [6..7] reserved [8 .. 8+kHistBins) histogram of iterations
+struct KernelArgs {
+    CameraParams cam;
+    MarchCfg cfg;
+    int32_t width, height, row0, rows;
+    int32_t tiles_x, tiles_y;
+    int32_t refill_min;
+    int32_t hist_bins;        // clamp for the LDS histogram (<= kHistBins)
+    float* depth;             // rows*width, t if hit else 0 (types.py:93), fp32
+    int32_t* iters;           // rows*width
+    uint8_t* hit;             // rows*width
+    double* t_raw;            // optional: raw fp64 t of every ray (parity tests)
+    double* final_sdf;        // optional: MarchResult.final_sdf (needs cfg.full)
+    long long* block_var;     // optional: (rows/4) x (width/8) variance numerators 32*sum(x^2)-sum(x)^2
+    unsigned long long* stats;
+};
+
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ int rank_in_mask(unsigned long long m)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+// t_raw / final_sdf are parity-test outputs (fp64, every ray): written straight to global
+// memory when requested, never staged (they are not part of the 9 B/ray product path).
+__device__ __forceinline__ void store_raw(const KernelArgs& a, int x0, int y0, int pix, const Result& r)
+{
+    if (a.t_raw || a.final_sdf) {
+        const size_t gi = (size_t)(y0 + (pix >> 6)) * (size_t)a.width + (size_t)(x0 + (pix & 63));
+        if (a.t_raw) a.t_raw[gi] = r.t;
+        if (a.final_sdf) a.final_sdf[gi] = r.final_sdf;
+    }
+}
+
+template <class Scene, class Strat, int TILE_H>
+__global__ __launch_bounds__(64) void render_kernel(const KernelArgs a)
+{
+    constexpr int TILE_PIX = kTileW * TILE_H;
+    __shared__ float s_depth[TILE_PIX];
+    __shared__ int32_t s_iters[TILE_PIX];
+    __shared__ uint8_t s_hit[TILE_PIX];
+    __shared__ unsigned int s_hist[kHistBins];
+
+    const int lane = lane_id();
+    const int ntiles = a.tiles_x * a.tiles_y;
+
+    for (int b = lane; b < kHistBins; b += 64) s_hist[b] = 0u;
+
+    unsigned long long acc_hits = 0, acc_iters = 0, acc_rays = 0;
+    int acc_max = 0, acc_min = 0x7fffffff;
+
+    const MarchCfg cfg = a.cfg;
+    vec3 origin = v3(a.cam.v[0], a.cam.v[1], a.cam.v[2]);
+
+    for (;;) {
+        int tile = 0;
+        if (lane == 0) tile = (int)atomicAdd(&a.stats[0], 1ull);
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        if (tile >= ntiles) break;   // uniform exit, reached by every wave
+
+        const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+        const int x0 = tx * kTileW;
+        const int y0 = ty * TILE_H;                 // relative to row0
+        // pixels of this tile that exist in the frame slice
+        const int tw = min(kTileW, a.width - x0);
+        const int th = min(TILE_H, a.rows - y0);
+
+        int pool_next = 0;            // wave-uniform: next unassigned tile-local pixel id
+        bool active = false;
+        int my_pix = 0;               // tile-linear index y*64+x of the ray this lane carries
+        vec3 dir = v3(0.0, 0.0, 0.0);
+        Strat s;
+
+        for (;;) {
+            const unsigned long long idle = __ballot(!active);
+            const int nidle = __popcll(idle);
+            if (pool_next < TILE_PIX && (nidle >= a.refill_min || nidle == 64)) {
+                if (!active) {
+                    // block-major pixel order: 32 consecutive ids form one 8x4 block, so a
+                    // wave starts on a compact 16x4 patch (coherent rays, similar trip counts)
+                    const int id = pool_next + rank_in_mask(idle);
+                    const int blk = id >> 5, within = id & 31;
+                    const int px = (blk & 7) * 8 + (within & 7);
+                    const int py = (blk >> 3) * 4 + (within >> 3);
+                    if (id < TILE_PIX && px < tw && py < th) {
+                        my_pix = py * kTileW + px;
+                        vec3 o_unused;
+                        camera_ray(a.cam, a.width, a.height, x0 + px, a.row0 + y0 + py, o_unused, dir);
+                        active = true;
+                        if (s.start(cfg)) {
+                            active = false;
+                            s_depth[my_pix] = s.res.hit ? (float)s.res.t : 0.0f;
+                            s_iters[my_pix] = s.res.iters;
+                            s_hit[my_pix] = (uint8_t)s.res.hit;
+                            store_raw(a, x0, y0, my_pix, s.res);
+                        }
+                    }
+                }
+                pool_next += nidle;
+            }
+            if (!__any(active)) {
+                if (pool_next >= TILE_PIX) break;
+                continue;
+            }
+            if (active) {
+                const double d = Scene::sdf(origin + dir * s.te);   // ray.py:15-17
+                if (s.step(d, cfg)) {
+                    active = false;
+                    s_depth[my_pix] = s.res.hit ? (float)s.res.t : 0.0f;   // types.py:93
+                    s_iters[my_pix] = s.res.iters;
+                    s_hit[my_pix] = (uint8_t)s.res.hit;
+                    store_raw(a, x0, y0, my_pix, s.res);
+                }
+            }
+        }
+        __syncthreads();   // single-wave workgroup: orders the staged LDS results before the flush
+
+        // ---- flush: lane == column; one 64-pixel row per store instruction ----------
+        const int gx = x0 + lane;
+        const bool col_ok = lane < tw;
+        long long bs = 0, bq = 0;   // per-column sums for the 8x4 block statistic
+#pragma unroll
+        for (int r = 0; r < TILE_H; ++r) {
+            if (r < th && col_ok) {
+                const int li = r * kTileW + lane;
+                const size_t gi = (size_t)(y0 + r) * (size_t)a.width + (size_t)gx;
+                const int it = s_iters[li];
+                const int h = s_hit[li];
+                a.depth[gi] = s_depth[li];
+                a.iters[gi] = it;
+                a.hit[gi] = (uint8_t)h;
+                acc_hits += (unsigned)h;
+                acc_iters += (unsigned)it;
+                acc_rays += 1;
+                acc_max = max(acc_max, it);
+                acc_min = min(acc_min, it);
+                atomicAdd(&s_hist[min(it, a.hist_bins - 1)], 1u);
+                bs += it;
+                bq += (long long)it * it;
+            }
+            if ((r & 3) == 3) {
+                // reduce the 8 columns of each 8x4 block (lanes 8k..8k+7)
+                long long S = bs, Q = bq;
+                S += __shfl_xor(S, 1); Q += __shfl_xor(Q, 1);
+                S += __shfl_xor(S, 2); Q += __shfl_xor(Q, 2);
+                S += __shfl_xor(S, 4); Q += __shfl_xor(Q, 4);
+                const int brow = y0 + (r - 3);              // first row of this block, relative to row0
+                if (a.block_var && (lane & 7) == 0 && gx + 8 <= a.width && brow + 4 <= a.rows &&
+                    a.row0 + brow + 4 <= a.height) {
+                    // full blocks only (types.py:128-131)
+                    a.block_var[(size_t)(brow >> 2) * (size_t)(a.width >> 3) + (size_t)(gx >> 3)] = 32 * Q - S * S;
+                }
+                bs = 0; bq = 0;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- per-wave totals -> one atomic each; histogram flush -----------------------
+    for (int off = 32; off > 0; off >>= 1) {
+        acc_hits += __shfl_xor(acc_hits, off);
+        acc_iters += __shfl_xor(acc_iters, off);
+        acc_rays += __shfl_xor(acc_rays, off);
+        acc_max = max(acc_max, __shfl_xor(acc_max, off));
+        acc_min = min(acc_min, __shfl_xor(acc_min, off));
+    }
+    if (lane == 0 && acc_rays) {
+        atomicAdd(&a.stats[1], acc_hits);
+        atomicAdd(&a.stats[2], acc_iters);
+        atomicMax(&a.stats[3], (unsigned long long)acc_max);
+        atomicMax(&a.stats[4], (unsigned long long)(0x7fffffff - acc_min));   // zero-initialised => store the complement
+        atomicAdd(&a.stats[5], acc_rays);
+    }
+    __syncthreads();
+    for (int b = lane; b < kHistBins; b += 64) {
+        const unsigned int c = s_hist[b];
+        if (c) atomicAdd(&a.stats[8 + b], (unsigned long long)c);
+    }
+}
+
+// ---- test entry points: explicit points / rays, one per thread ----------------------
+
+template <class Scene>
+__global__ void sdf_eval_kernel(const double* __restrict__ xyz, size_t n, double* __restrict__ out)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = Scene::sdf(v3(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]));
+}
+
+template <class Scene, class Strat>
+__global__ void march_rays_kernel(MarchCfg cfg, const double* __restrict__ origins, const double* __restrict__ dirs,
+                                  size_t n, uint8_t* hit, double* t, int32_t* iters, double* final_sdf)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    vec3 o = v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
+    vec3 d = normalized(v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]));   // Ray.__init__ normalises
+    Result r = march_one<Scene, Strat>(o, d, cfg);
+    hit[i] = (uint8_t)r.hit; t[i] = r.t; iters[i] = r.iters; final_sdf[i] = r.final_sdf;
+}
+
+// Per-scene launch table, filled by rm_scene_tu.hip (one translation unit per scene).
+struct SceneLaunchers {
+    hipError_t (*render)(int strategy, int tile_h, const KernelArgs& a, int grid, hipStream_t s);
+    hipError_t (*occupancy)(int strategy, int tile_h, int* blocks_per_cu);
+    hipError_t (*sdf_eval)(const double* xyz, size_t n, double* out, hipStream_t s);
+    hipError_t (*march_rays)(int strategy, const MarchCfg& cfg, const double* o, const double* d, size_t n,
+                             uint8_t* hit, double* t, int32_t* iters, double* fs, hipStream_t s);
+};
+
+}  // namespace rm

@@ -1,0 +1,85 @@
+// rm_scene_tu.hip -- one translation unit per scene (compile with -DRM_SCENE_ID=<0..19>).
+// Instantiates render / march_rays kernels for every strategy and the sdf_eval kernel
+// of that scene, and exports their launchers through rm::scene_launchers_<id>().
+#include "rm_kernels.h"
+
+#ifndef RM_SCENE_ID
+#error "compile with -DRM_SCENE_ID=<scene id>"
+#endif
+
+namespace rm {
+
+template <int ID> struct SceneById;
+#define RM_X(id, S) template <> struct SceneById<id> { using type = S; };
+RM_SCENE_LIST(RM_X)
+#undef RM_X
+using SceneT = SceneById<RM_SCENE_ID>::type;
+
+template <class Strat, int TH>
+static hipError_t launch_render(const KernelArgs& a, int grid, hipStream_t s)
+{
+    hipLaunchKernelGGL((render_kernel<SceneT, Strat, TH>), dim3(grid), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+template <class Strat, int TH>
+static hipError_t occ_render(int* blocks)
+{
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, render_kernel<SceneT, Strat, TH>, 64, 0);
+}
+
+static hipError_t render(int strategy, int tile_h, const KernelArgs& a, int grid, hipStream_t s)
+{
+    switch (strategy) {
+#define RM_X(id, S) \
+    case id: return tile_h == 4 ? launch_render<S, 4>(a, grid, s) : launch_render<S, 8>(a, grid, s);
+        RM_STRATEGY_LIST(RM_X)
+#undef RM_X
+    }
+    return hipErrorInvalidValue;
+}
+
+static hipError_t occupancy(int strategy, int tile_h, int* blocks)
+{
+    switch (strategy) {
+#define RM_X(id, S) \
+    case id: return tile_h == 4 ? occ_render<S, 4>(blocks) : occ_render<S, 8>(blocks);
+        RM_STRATEGY_LIST(RM_X)
+#undef RM_X
+    }
+    return hipErrorInvalidValue;
+}
+
+static hipError_t sdf_eval(const double* xyz, size_t n, double* out, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL((sdf_eval_kernel<SceneT>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, xyz, n, out);
+    return hipGetLastError();
+}
+
+static hipError_t march_rays(int strategy, const MarchCfg& cfg, const double* o, const double* d, size_t n,
+                             uint8_t* hit, double* t, int32_t* iters, double* fs, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    dim3 grid((unsigned)((n + 63) / 64)), block(64);
+    switch (strategy) {
+#define RM_X(id, S)                                                                                        \
+    case id:                                                                                               \
+        hipLaunchKernelGGL((march_rays_kernel<SceneT, S>), grid, block, 0, s, cfg, o, d, n, hit, t, iters, fs); \
+        return hipGetLastError();
+        RM_STRATEGY_LIST(RM_X)
+#undef RM_X
+    }
+    return hipErrorInvalidValue;
+}
+
+#define RM_CAT2(a, b) a##b
+#define RM_CAT(a, b) RM_CAT2(a, b)
+// a host function (not a const global: hipcc would try to emit that for the device too)
+const SceneLaunchers* RM_CAT(scene_launchers_, RM_SCENE_ID)()
+{
+    static const SceneLaunchers l = { render, occupancy, sdf_eval, march_rays };
+    return &l;
+}
+
+}  // namespace rm

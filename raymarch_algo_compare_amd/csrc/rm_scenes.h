@@ -1,0 +1,287 @@
+// rm_scenes.h -- the 20 catalogue scenes as inlinable functors (one per scene id).
+//
+// Scene ids follow get_all_scenes() (scenes/catalog.py:640-663).  Each sdf() keeps
+// the reference's evaluation order (IEEE binary64, no contraction).  `x ** 0.5`,
+// `x ** 2`, `r ** 7.0` ... are float_pow in the reference and therefore rm_pow here.
+#pragma once
+
+#include "rm_core.h"
+
+namespace rm {
+
+// ---- scenes/primitives.py -----------------------------------------------------
+
+RM_HD double sd_sphere(vec3 p, double radius) { return length(p) - radius; }            // :11-12
+
+RM_HD double sd_box(vec3 p, vec3 b)                                                      // :14-18
+{
+    vec3 q = v3(rm_fabs(p.x) - b.x, rm_fabs(p.y) - b.y, rm_fabs(p.z) - b.z);
+    double outside = length(v3(py_max(q.x, 0.0), py_max(q.y, 0.0), py_max(q.z, 0.0)));
+    double inside = py_min(py_max(q.x, py_max(q.y, q.z)), 0.0);
+    return outside + inside;
+}
+
+RM_HD double sd_plane(vec3 p, vec3 n, double offset) { return dot(p, n) - offset; }      // :20-21
+
+RM_HD double sd_cylinder(vec3 p, double radius, double half_height)                      // :23-28
+{
+    double d_radial = rm_pow(p.x * p.x + p.z * p.z, 0.5) - radius;
+    double d_height = rm_fabs(p.y) - half_height;
+    double outside = rm_pow(rm_pow(py_max(d_radial, 0.0), 2.0) + rm_pow(py_max(d_height, 0.0), 2.0), 0.5);
+    double inside = py_min(py_max(d_radial, d_height), 0.0);
+    return outside + inside;
+}
+
+RM_HD double sd_torus(vec3 p, double major_radius, double minor_radius)                  // :30-32
+{
+    double q_xz = rm_pow(p.x * p.x + p.z * p.z, 0.5) - major_radius;
+    return rm_pow(q_xz * q_xz + p.y * p.y, 0.5) - minor_radius;
+}
+
+RM_HD double sd_capped_torus(vec3 p, double sc0, double sc1, double ra, double rb)       // :41-50
+{
+    double px = rm_fabs(p.x);
+    double k;
+    if (sc1 * px > sc0 * p.y)
+        k = px * sc0 + p.y * sc1;
+    else
+        k = rm_pow(px * px + p.y * p.y, 0.5);
+    return rm_pow(p.x * p.x + p.y * p.y + p.z * p.z + ra * ra - 2.0 * ra * k, 0.5) - rb;
+}
+
+RM_HD double op_smooth_union(double d1, double d2, double k)                             // :80-86
+{
+    double h = py_max(0.0, py_min(1.0, 0.5 + 0.5 * (d2 - d1) / k));
+    return (d2 * (1.0 - h) + d1 * h) - k * h * (1.0 - h);
+}
+
+// op_repeat (:102-108), one axis, spacing > 0 and a power of two
+RM_HD double repeat_axis(double x, double spacing)
+{
+    return py_mod_pow2(x + spacing * 0.5, spacing) - spacing * 0.5;
+}
+
+// ---- scenes/catalog.py ----------------------------------------------------------
+
+struct SceneSphere {                                                                     // :25-26
+    static RM_HD double sdf(vec3 p) { return sd_sphere(p, 1.0); }
+};
+struct SceneGrazingPlane {                                                               // :44-45
+    static RM_HD double sdf(vec3 p) { return sd_plane(p, v3(0.0, 1.0, 0.0), -0.5); }
+};
+struct SceneCube {                                                                       // :68-69
+    static RM_HD double sdf(vec3 p) { return sd_box(p, v3(1.0, 1.0, 1.0)); }
+};
+struct SceneThinTorus {                                                                  // :87-88
+    static RM_HD double sdf(vec3 p) { return sd_torus(p, 1.5, 0.05); }
+};
+struct SceneCylinder {                                                                   // :105-106
+    static RM_HD double sdf(vec3 p) { return sd_cylinder(p, 1.0, 1.5); }
+};
+struct SceneNearMiss {                                                                   // :124-127
+    static RM_HD double sdf(vec3 p)
+    {
+        double d1 = sd_sphere(p - v3(-1.01, 0.0, 0.0), 1.0);
+        double d2 = sd_sphere(p - v3(1.01, 0.0, 0.0), 1.0);
+        return py_min(d1, d2);
+    }
+};
+struct SceneHollowCube {                                                                 // :145-148
+    static RM_HD double sdf(vec3 p)
+    {
+        double d_box = sd_box(p, v3(1.0, 1.0, 1.0));
+        double d_sphere = sd_sphere(p, 1.3);
+        return py_max(d_box, -d_sphere);
+    }
+};
+struct SceneSmoothBlend {                                                                // :166-169
+    static RM_HD double sdf(vec3 p)
+    {
+        double d1 = sd_sphere(p - v3(-0.5, 0.0, 0.0), 0.8);
+        double d2 = sd_box(p - v3(0.5, 0.0, 0.0), v3(0.6, 0.6, 0.6));
+        return op_smooth_union(d1, d2, 0.5);
+    }
+};
+struct SceneOnionShell {                                                                 // :187-191
+    static RM_HD double sdf(vec3 p)
+    {
+        double d = sd_sphere(p, 2.0);
+        d = rm_fabs(d) - 0.1;
+        d = rm_fabs(d) - 0.05;
+        return d;
+    }
+};
+struct SceneMenger {                                                                     // :212-241 (iterations=3)
+    static RM_HD double sdf(vec3 p)
+    {
+        double d = sd_box(p, v3(1.0, 1.0, 1.0));
+        double s = 1.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            vec3 a = v3(py_mod_pow2(p.x * s, 2.0) - 1.0, py_mod_pow2(p.y * s, 2.0) - 1.0,
+                        py_mod_pow2(p.z * s, 2.0) - 1.0);
+            s *= 3.0;
+            vec3 r = v3(rm_fabs(1.0 - 3.0 * rm_fabs(a.x)), rm_fabs(1.0 - 3.0 * rm_fabs(a.y)),
+                        rm_fabs(1.0 - 3.0 * rm_fabs(a.z)));
+            double da = py_max(r.x, r.y);
+            double db = py_max(r.y, r.z);
+            double dc = py_max(r.z, r.x);
+            double c = (py_min(da, py_min(db, dc)) - 1.0) / s;
+            d = py_max(d, c);
+        }
+        return d;
+    }
+};
+struct SceneMandelbulb {                                                                 // :266-293 (power 8, 8 iterations)
+    static RM_HD double sdf(vec3 p)
+    {
+        const double power = 8.0;
+        vec3 z = p;
+        double dr = 1.0, r = 0.0;
+        for (int i = 0; i < 8; ++i) {
+            r = length(z);
+            if (r > 4.0) break;
+            double theta = rm_acos(py_max(-1.0, py_min(1.0, z.z / py_max(r, 1e-12))));
+            double phi = rm_atan2(z.y, z.x);
+            dr = rm_pow(r, power - 1.0) * power * dr + 1.0;
+            double zr = rm_pow(r, power);
+            theta *= power;
+            phi *= power;
+            double st = rm_sin(theta), ct = rm_cos(theta), sp = rm_sin(phi), cp = rm_cos(phi);
+            z = v3(zr * st * cp, zr * st * sp, zr * ct) + p;
+        }
+        return 0.5 * rm_log(py_max(r, 1e-12)) * r / py_max(dr, 1e-12);
+    }
+};
+struct SceneBadLipschitz {                                                               // :320-321
+    static RM_HD double sdf(vec3 p) { return (length(p) - 1.0) * 2.0; }
+};
+struct ScenePillars {                                                                    // :339-344
+    static RM_HD double sdf(vec3 p)
+    {
+        vec3 q = v3(repeat_axis(p.x, 2.0), p.y, repeat_axis(p.z, 2.0));
+        double d_pillar = sd_cylinder(q, 0.15, 3.0);
+        double d_floor = sd_plane(p, v3(0.0, 1.0, 0.0), -3.0);
+        return py_min(d_pillar, d_floor);
+    }
+};
+struct SceneThinPlanes {                                                                 // :368-377
+    static RM_HD double sdf(vec3 p)
+    {
+        const double spacing = 0.5;
+        double py_m = py_mod_pow2(p.y + spacing * 0.5, spacing) - spacing * 0.5;
+        vec3 q = v3(p.x, py_m, p.z);
+        return rm_fabs(sd_plane(q, v3(0.0, 1.0, 0.0), 0.0)) - 0.01;
+    }
+};
+
+// (center, radius) tables of Sphere Cloud (:401-414) and Bumpy Sphere (:450-461).
+// Written as unrolled literal lists so they live in the instruction stream / SGPRs.
+#define RM_CLOUD_LIST(X)                                                                   \
+    X(0.4253, 1.3505, 0.9373, 0.4723) X(-0.9343, -0.6794, 1.2701, 0.4257)                 \
+    X(-1.6821, 1.0922, 1.0100, 0.3090) X(-0.1090, -0.6697, -0.7534, 0.4659)               \
+    X(-0.8334, -0.1867, 0.0155, 0.4879) X(0.1819, 1.6847, 0.9951, 0.4789)                 \
+    X(0.4154, 1.6625, -0.9680, 0.4053) X(-1.1553, 0.3826, -1.5506, 0.3120)                \
+    X(-1.5787, 0.0506, -0.1149, 0.3223) X(1.4184, 0.4394, 0.0480, 0.4841)                 \
+    X(-0.0106, -0.8584, -1.6599, 0.4015) X(-1.0458, 0.6529, -1.0179, 0.3197)              \
+    X(-0.4436, -1.6873, 1.1222, 0.4745) X(-1.1748, -0.7902, 1.2931, 0.4211)               \
+    X(0.0333, 1.1803, 0.4750, 0.4053) X(0.8220, -1.3889, 0.1399, 0.3628)                  \
+    X(0.0264, 1.2626, -0.4717, 0.3704) X(0.3338, -1.4985, -0.3821, 0.3327)                \
+    X(-0.6017, -1.1893, 1.0755, 0.2884) X(-0.4099, 1.6277, 0.3060, 0.4728)                \
+    X(0.3572, 0.4692, 0.5999, 0.3829) X(-1.1873, -0.2029, -0.8855, 0.4005)                \
+    X(-0.3315, -1.3712, 1.5906, 0.3509) X(-0.9690, 0.5840, -0.6786, 0.4453)
+
+struct SceneSphereCloud {                                                                // :424-428
+    static RM_HD double sdf(vec3 p)
+    {
+        double d = 1e10;
+#define RM_X(cx, cy, cz, r) d = py_min(d, sd_sphere(p - v3(cx, cy, cz), r));
+        RM_CLOUD_LIST(RM_X)
+#undef RM_X
+        return d;
+    }
+};
+
+#define RM_BUMP_LIST(X)                                                                    \
+    X(0.3841, 1.4500, 0.0000) X(-0.4821, 1.3500, 0.4417) X(0.0725, 1.2500, -0.8260)       \
+    X(0.5860, 1.1500, 0.7643) X(-1.0548, 1.0500, -0.1866) X(0.9794, 0.9500, -0.6230)      \
+    X(-0.3209, 0.8500, 1.1935) X(-0.5987, 0.7500, -1.1528) X(1.2698, 0.6500, 0.4637)      \
+    X(-1.2900, 0.5500, 0.5325) X(0.6065, 0.4500, -1.2960) X(0.4365, 0.3500, 1.3917)       \
+    X(-1.2797, 0.2500, -0.7416) X(1.4577, 0.1500, -0.3205) X(-0.8622, 0.0500, 1.2264)     \
+    X(-0.1927, -0.0500, -1.4867) X(1.1412, -0.1500, 0.9618) X(-1.4778, -0.2500, 0.0611)   \
+    X(1.0339, -0.3500, -1.0289) X(-0.0661, -0.4500, 1.4294) X(-0.8941, -0.5500, -1.0715)  \
+    X(1.3398, -0.6500, 0.1803) X(-1.0663, -0.7500, 0.7419) X(0.2713, -0.8500, -1.2058)    \
+    X(0.5771, -0.9500, 1.0072) X(-1.0205, -1.0500, -0.3256) X(0.8743, -1.1500, -0.4039)   \
+    X(-0.3201, -1.2500, 0.7649) X(-0.2213, -1.3500, -0.6152) X(0.3400, -1.4500, 0.1787)
+
+struct SceneBumpySphere {                                                                // :471-475
+    static RM_HD double sdf(vec3 p)
+    {
+        double d = sd_sphere(p, 1.4);
+#define RM_X(cx, cy, cz) d = py_min(d, sd_sphere(p - v3(cx, cy, cz), 0.18));
+        RM_BUMP_LIST(RM_X)
+#undef RM_X
+        return d;
+    }
+};
+
+struct SceneGyroid {                                                                     // :496-517
+    static RM_HD double sdf(vec3 p)
+    {
+        const double FREQ = 3.0;
+        const double LIP = 0x1.4c8dc2e423980p+3;  // 3.0 * 2.0 * (3.0 ** 0.5) as CPython evaluates it
+        double qx = FREQ * p.x, qy = FREQ * p.y, qz = FREQ * p.z;
+        double g = rm_sin(qx) * rm_cos(qy) + rm_sin(qy) * rm_cos(qz) + rm_sin(qz) * rm_cos(qx);
+        double sheet = g / LIP;
+        double ball = sd_sphere(p, 2.2);
+        return py_max(sheet, ball);
+    }
+};
+
+struct SceneCappedTorus {                                                                // :533-548
+    static RM_HD double sdf(vec3 p)
+    {
+        // SC = (math.sin(2.0), math.cos(2.0)) as glibc evaluates them
+        return sd_capped_torus(p, 0x1.d18f6ead1b446p-1, -0x1.aa22657537205p-2, 1.2, 0.2);
+    }
+};
+
+struct SceneBoxLattice {                                                                 // :581-590
+    static RM_HD double cell(double x)
+    {
+        double r = rm_floor(x / 1.0 + 0.5);
+        r = py_max(-2.0, py_min(2.0, r));
+        return r;
+    }
+    static RM_HD double sdf(vec3 p)
+    {
+        vec3 q = v3(p.x - 1.0 * cell(p.x), p.y - 1.0 * cell(p.y), p.z - 1.0 * cell(p.z));
+        return sd_box(q, v3(0.3, 0.3, 0.3));
+    }
+};
+
+struct SceneMetaballs {                                                                  // :608-633
+    static RM_HD double sdf(vec3 p)
+    {
+        const double K = 0.45;
+        double d = sd_sphere(p - v3(0.0, 0.0, 0.0), 0.8);
+        d = op_smooth_union(d, sd_sphere(p - v3(1.0, 0.0, 0.0), 0.6), K);
+        d = op_smooth_union(d, sd_sphere(p - v3(-1.0, 0.0, 0.0), 0.6), K);
+        d = op_smooth_union(d, sd_sphere(p - v3(0.0, 1.0, 0.0), 0.6), K);
+        d = op_smooth_union(d, sd_sphere(p - v3(0.0, -1.0, 0.0), 0.6), K);
+        d = op_smooth_union(d, sd_sphere(p - v3(0.0, 0.0, 1.0), 0.6), K);
+        return d;
+    }
+};
+
+#define RM_NUM_SCENES 20
+
+// X(id, functor) in registry order
+#define RM_SCENE_LIST(X)                                                                   \
+    X(0, SceneSphere) X(1, SceneGrazingPlane) X(2, SceneCube) X(3, SceneThinTorus)         \
+    X(4, SceneCylinder) X(5, SceneNearMiss) X(6, SceneHollowCube) X(7, SceneSmoothBlend)   \
+    X(8, SceneOnionShell) X(9, SceneMenger) X(10, SceneMandelbulb) X(11, SceneBadLipschitz)\
+    X(12, ScenePillars) X(13, SceneThinPlanes) X(14, SceneSphereCloud) X(15, SceneBumpySphere) \
+    X(16, SceneGyroid) X(17, SceneCappedTorus) X(18, SceneBoxLattice) X(19, SceneMetaballs)
+
+}  // namespace rm

@@ -1,0 +1,68 @@
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+# Scenes whose SDF reaches sin/cos/acos/atan2/log.  Until those routines are bit-exact
+# restatements of glibc's (DESIGN.md "math parity"), a few rays that amplify ulp noise may differ.
+TRANSCENDENTAL_SCENES = {10, 16}
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+class GoldenFrames:
+    """One frames_*.npz written by oracle/gen_golden.py (outputs of the reference itself)."""
+
+    def __init__(self, tag):
+        self.tag = tag
+        self.z = np.load(os.path.join(GOLDEN, f"frames_{tag}.npz"))
+        self.pairs = sorted({tuple(int(p[1:]) for p in k.split("_")[:2]) for k in self.z.files})
+        sp = os.path.join(GOLDEN, f"stats_{tag}.json")
+        self.stats = json.load(open(sp, encoding="utf-8")) if os.path.exists(sp) else {}
+
+    def get(self, sid, kid):
+        p = f"s{sid}_k{kid}_"
+        meta = self.z[p + "meta"]
+        W, H, row0, rows = (int(meta[i]) for i in range(4))
+        n = rows * W
+        hit = np.unpackbits(self.z[p + "hitbits"])[:n].reshape(rows, W).astype(np.uint8)
+        depth = np.zeros(n, dtype=np.float64)
+        depth[hit.reshape(-1) > 0] = self.z[p + "t_hit"]
+        return {
+            "W": W, "H": H, "row0": row0, "rows": rows, "max_iterations": int(meta[4]),
+            "hit_threshold": float(meta[5]), "max_distance": float(meta[6]), "lipschitz": float(meta[7]),
+            "cam": self.z[p + "cam"].copy(), "iters": self.z[p + "iters"].astype(np.int32), "hit": hit,
+            "depth": depth.reshape(rows, W), "sha_t": self.z[p + "sha_t"].tobytes(),
+            "sha_fs": self.z[p + "sha_fs"].tobytes(),
+        }
+
+
+def sha_f64(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype="<f8").tobytes()).digest()
+
+
+_cache = {}
+
+
+def golden_frames(tag):
+    if tag not in _cache:
+        _cache[tag] = GoldenFrames(tag)
+    return _cache[tag]
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The ctypes binding, initialised on cuda:0 -- fails (does not skip) without the HIP library."""
+    from raymarch_algo_compare_amd import _native
+    _native.init()
+    return _native

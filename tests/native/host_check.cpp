@@ -1,0 +1,68 @@
+// Host-only check build of the product's kernel headers (scenes, strategy state
+// machines, camera, math) -- compiled by g++ for tests ONLY, so the exact source
+// the gfx950 kernels are built from can be diffed against the oracle and the
+// reference goldens in a container without a GPU.  Never loaded by the product.
+#include <stddef.h>
+#include <stdint.h>
+#include "../../raymarch_algo_compare_amd/csrc/rm_camera.h"
+#include "../../raymarch_algo_compare_amd/csrc/rm_scenes.h"
+#include "../../raymarch_algo_compare_amd/csrc/rm_strategies.h"
+
+using namespace rm;
+
+template <class Scene, class Strat>
+static void render_t(const MarchCfg& cfg, const CameraParams& cam, int W, int H, int row0, int rows,
+                     uint8_t* hit, double* t, int32_t* iters, double* fs)
+{
+    for (int r = 0; r < rows; ++r)
+        for (int px = 0; px < W; ++px) {
+            vec3 o, d;
+            camera_ray(cam, W, H, px, row0 + r, o, d);
+            Result res = march_one<Scene, Strat>(o, d, cfg);
+            size_t k = (size_t)r * W + px;
+            hit[k] = (uint8_t)res.hit; t[k] = res.t; iters[k] = res.iters; fs[k] = res.final_sdf;
+        }
+}
+
+template <class Scene>
+static int render_s(int strategy, const MarchCfg& cfg, const CameraParams& cam, int W, int H, int row0, int rows,
+                    uint8_t* hit, double* t, int32_t* iters, double* fs)
+{
+    switch (strategy) {
+#define RM_X(id, S) case id: render_t<Scene, S>(cfg, cam, W, H, row0, rows, hit, t, iters, fs); return 0;
+        RM_STRATEGY_LIST(RM_X)
+#undef RM_X
+    }
+    return -2;
+}
+
+extern "C" {
+
+int rmh_render(int scene, int strategy, int max_iterations, double hit_threshold, double max_distance,
+               double lipschitz, int full, const double* cam14, int W, int H, int row0, int rows,
+               uint8_t* hit, double* t, int32_t* iters, double* fs)
+{
+    MarchCfg cfg;
+    cfg.hit_threshold = hit_threshold; cfg.max_distance = max_distance; cfg.lipschitz = lipschitz;
+    cfg.max_iterations = max_iterations; cfg.full = full;
+    CameraParams cam;
+    for (int i = 0; i < 14; ++i) cam.v[i] = cam14[i];
+    switch (scene) {
+#define RM_X(id, S) case id: return render_s<S>(strategy, cfg, cam, W, H, row0, rows, hit, t, iters, fs);
+        RM_SCENE_LIST(RM_X)
+#undef RM_X
+    }
+    return -1;
+}
+
+int rmh_sdf_eval(int scene, const double* xyz, size_t n, double* out)
+{
+    switch (scene) {
+#define RM_X(id, S) case id: for (size_t i = 0; i < n; ++i) out[i] = S::sdf(v3(xyz[3*i], xyz[3*i+1], xyz[3*i+2])); return 0;
+        RM_SCENE_LIST(RM_X)
+#undef RM_X
+    }
+    return -1;
+}
+
+}

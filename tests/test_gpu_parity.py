@@ -1,0 +1,122 @@
+"""HIP kernels vs the reference's golden vectors (through the C ABI, rm_render / rm_sdf_eval /
+rm_march_rays).  Bar: iterations and hit masks bit-exact, fp32 depth within 1e-5 abs of the
+reference's float64 depth (north_star), raw fp64 t and final_sdf bit-exact (sha256) on every
+scene whose math is an exact restatement."""
+import numpy as np
+import pytest
+
+from conftest import TRANSCENDENTAL_SCENES, golden_frames, sha_f64
+
+pytestmark = pytest.mark.gpu
+
+DEPTH_TOL = 1e-5   # abs, fp32 depth vs reference float64 depth (BASELINE.json north_star)
+
+
+def _render(hip, g, sid, kid, full, **tuning):
+    desc = hip.make_desc(sid, kid, g["cam"], g["W"], g["H"], g["row0"], g["rows"], g["max_iterations"],
+                         g["hit_threshold"], g["max_distance"], g["lipschitz"], full, **tuning)
+    return hip.render(desc, want_t_raw=True, want_final_sdf=full, want_block_var=(g["row0"] % 4 == 0))
+
+
+def _check(out, g, sid, exact_raw=True):
+    bad_it = int((out["iters"] != g["iters"]).sum())
+    bad_hit = int((out["hit"] != g["hit"]).sum())
+    if sid in TRANSCENDENTAL_SCENES:
+        # platform (OCML) transcendentals: report, and bound, the unstable rays
+        n = g["iters"].size
+        assert bad_it <= max(2, n // 200) and bad_hit <= max(2, n // 1000), (bad_it, bad_hit)
+        ok = (out["hit"] == g["hit"]) & (out["iters"] == g["iters"]) & (g["hit"] > 0)
+        return bad_it, bad_hit
+    assert bad_it == 0 and bad_hit == 0, f"iteration mismatches {bad_it}, hit mismatches {bad_hit}"
+    err = np.abs(out["depth"].astype(np.float64) - g["depth"]).max()
+    assert err <= DEPTH_TOL, f"max abs depth error {err}"
+    if exact_raw:
+        assert sha_f64(out["t_raw"]) == g["sha_t"], "raw fp64 t differs from the reference"
+        if out["final_sdf"] is not None:
+            assert sha_f64(out["final_sdf"]) == g["sha_fs"], "final_sdf differs from the reference"
+    st = out["stats"]
+    assert st["total_rays"] == g["iters"].size
+    assert st["hit_count"] == int(g["hit"].sum()) and st["sum_iters"] == int(g["iters"].sum())
+    assert st["iter_max"] == int(g["iters"].max()) and st["iter_min"] == int(g["iters"].min())
+    hist = np.bincount(g["iters"].reshape(-1), minlength=len(st["iter_hist"]))
+    assert (st["iter_hist"] == hist).all()
+    return 0, 0
+
+
+@pytest.mark.parametrize("full", [True, False])
+def test_all_pairs_64x48(hip, full):
+    """Every (scene, strategy) of the 20 x 11 registry at 64x48, reference camera wiring."""
+    G = golden_frames("64x48")
+    unstable = {}
+    for sid, kid in G.pairs:
+        g = G.get(sid, kid)
+        out = _render(hip, g, sid, kid, full)
+        u = _check(out, g, sid)
+        if u != (0, 0):
+            unstable[(sid, kid)] = u
+    print("unstable (scene, strategy) -> (iter, hit) mismatches:", unstable)
+
+
+def test_graded_160x120(hip):
+    G = golden_frames("160x120")
+    for sid, kid in G.pairs:
+        g = G.get(sid, kid)
+        _check(_render(hip, g, sid, kid, True), g, sid)
+
+
+def test_rows_of_1080p(hip):
+    """Rows 536..543 of the 1920x1080 frame: full-resolution pixel indexing + row sharding."""
+    G = golden_frames("rows1080")
+    for sid, kid in G.pairs:
+        g = G.get(sid, kid)
+        _check(_render(hip, g, sid, kid, True), g, sid)
+
+
+def test_leaked_camera(hip):
+    """Cube seen through the Grazing Plane camera (the reference CLI's camera leak)."""
+    G = golden_frames("leak")
+    g = G.get(2, 0)
+    _check(_render(hip, g, 2, 0, True), g, 2)
+
+
+def test_reference_smoke_config(hip):
+    """The reference's own smoke test shape (tests/test_smoke.py:31-43): 16x12, max_iterations=100."""
+    G = golden_frames("16x12_it100")
+    for sid, kid in G.pairs:
+        g = G.get(sid, kid)
+        out = _render(hip, g, sid, kid, True)
+        _check(out, g, sid)
+        assert out["stats"]["hit_count"] > 0 and out["iters"].max() <= 100 + 9
+
+
+@pytest.mark.parametrize("tuning", [dict(tile_rows=8), dict(refill_min=1), dict(refill_min=64), dict(grid_waves=3)])
+def test_schedule_invariance(hip, tuning):
+    """Tile shape, refill threshold and grid size change the schedule, never the results."""
+    G = golden_frames("160x120")
+    for sid, kid in [(0, 0), (2, 10), (9, 6), (12, 0)]:
+        g = G.get(sid, kid)
+        _check(_render(hip, g, sid, kid, False, **tuning), g, sid)
+
+
+def test_sdf_points(hip):
+    import os
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "sdf_points.npz"))
+    for sid in range(20):
+        got = hip.sdf_eval(sid, z["pts"])
+        ref = z[f"s{sid}"]
+        if sid in TRANSCENDENTAL_SCENES:
+            assert np.abs(got - ref).max() < 1e-12
+        else:
+            assert (got.view(np.uint64) == ref.view(np.uint64)).all(), f"scene {sid}"
+
+
+def test_block_var_matches_reference_proxy(hip):
+    from raymarch_algo_compare_amd.stats import warp_divergence_from_block_var, warp_divergence_proxy
+    G = golden_frames("64x48")
+    for sid, kid in [(0, 0), (2, 6), (9, 10), (12, 0)]:
+        g = G.get(sid, kid)
+        out = _render(hip, g, sid, kid, False)
+        want = G.stats[f"s{sid}_k{kid}"]["warp_divergence_proxy"]
+        assert warp_divergence_from_block_var(out["block_var"]) == want
+        assert warp_divergence_proxy(out["iters"]) == want
