@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the sphere-tracing path on MI355X.
+
+Metric (BASELINE.json): Mrays/s + mean iterations/ray, 1920x1080 Mandelbulb / Standard, fp64
+parity arithmetic, 1/2/4/8 GPUs.  A "step" is one frame render (one launch of the
+(Mandelbulb, Standard) kernel writing depth/iterations/hit into HBM-resident buffers).
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Workloads (--workload):
+  mandelbulb-1080p  (default) every rank renders a full 1920x1080 frame per step: the rays of an
+                    N-frame batch are sharded one frame per GPU, no data-path collective (weak scaling).
+  rowshard-8k       BASELINE config 5: ONE 7680x4320 frame per step, rows dealt band-cyclically to
+                    the ranks, the three maps all-gathered with RCCL over xGMI (strong scaling).
+
+The timed region holds exactly K steps between barrier + torch.cuda.synchronize(); rank 0 prints
+ONE JSON line.  `roofline` prices the render kernel against HBM (9 algorithmic bytes per ray; the
+kernel is fp64-VALU/latency bound, so the fraction is tiny by construction -- DESIGN.md) and
+`cpu_baseline` times the CPU oracle (oracle/, test infrastructure) on the host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X vector fp64 spec peak (half the 157.3 TF fp32 vector rate)
+BYTES_PER_RAY = 9               # fp32 depth + int32 iterations + uint8 hit
+
+WORKLOADS = {
+    "mandelbulb-1080p": dict(scene=10, strategy="Standard", width=1920, height=1080, sharded=False),
+    "rowshard-8k": dict(scene=10, strategy="Standard", width=7680, height=4320, sharded=True),
+    "pillars-8k": dict(scene=12, strategy="Standard", width=7680, height=4320, sharded=True),
+}
+
+
+def cpu_baseline(scene_id, strategy_id, cam14, width, height, lipschitz):
+    """Oracle (CPU restatement of the reference, oracle/rm_oracle.c) on a bounded sample of the
+    same workload: all host threads on the middle 256 rows + one thread on 24 of them."""
+    from oracle import oracle
+    threads = max(1, min(os.cpu_count() or 1, 64))
+    rows_mt = min(height, 256)
+    r0 = (height - rows_mt) // 2
+    t0 = time.perf_counter()
+    fr = oracle.render(scene_id, strategy_id, cam14, width, height, row0=r0, rows=rows_mt, lipschitz=lipschitz,
+                       nthreads=threads)
+    dt = time.perf_counter() - t0
+    rows_1t = min(height, 24)
+    r1 = (height - rows_1t) // 2
+    t1 = time.perf_counter()
+    oracle.render(scene_id, strategy_id, cam14, width, height, row0=r1, rows=rows_1t, lipschitz=lipschitz, nthreads=1)
+    dt1 = time.perf_counter() - t1
+    return {
+        "value": rows_mt * width / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "sample": f"rows {r0}..{r0 + rows_mt - 1} of the {width}x{height} frame ({rows_mt * width} rays, "
+                  f"{dt:.2f} s, OpenMP over rows); mean iters/ray of the sample {float(fr.iters.mean()):.2f}",
+        "single_thread_us_per_ray": dt1 / (rows_1t * width) * 1e6,
+        "single_thread_sample": f"rows {r1}..{r1 + rows_1t - 1}, {dt1:.2f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="mandelbulb-1080p", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tile-rows", type=int, default=0)
+    ap.add_argument("--refill-min", type=int, default=0)
+    ap.add_argument("--grid-waves", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from raymarch_algo_compare_amd import _native, registry, sharding
+    from raymarch_algo_compare_amd.camera import Camera
+
+    L = _native.init(local_rank)
+    wl = WORKLOADS[args.workload]
+    scene = registry.SCENES[wl["scene"]]
+    strat_id = registry.STRATEGIES[wl["strategy"]]
+    W, H = wl["width"], wl["height"]
+    cam = Camera(scene.camera_position or (0.0, 0.0, 5.0), scene.camera_target or (0.0, 0.0, 0.0),
+                 (0.0, 1.0, 0.0), 60.0, W, H).params14()
+    lip = scene.lipschitz if (wl["strategy"] == "Segment" and scene.lipschitz) else 1.0
+    tuning = dict(tile_rows=args.tile_rows, refill_min=args.refill_min, grid_waves=args.grid_waves)
+    if wl["sharded"]:
+        plan = sharding.plan_rows(H, world, rank)
+        desc = _native.make_desc(scene.id, strat_id, cam, W, H, lipschitz=lip, **tuning, **plan.desc_kwargs())
+        rows_local = plan.rows
+    else:
+        plan = None
+        desc = _native.make_desc(scene.id, strat_id, cam, W, H, lipschitz=lip, **tuning)
+        rows_local = H
+
+    dev = torch.device("cuda", local_rank)
+    d_depth = torch.empty((rows_local, W), dtype=torch.float32, device=dev)
+    d_iters = torch.empty((rows_local, W), dtype=torch.int32, device=dev)
+    d_hit = torch.empty((rows_local, W), dtype=torch.uint8, device=dev)
+    d_stats = torch.zeros(L.rm_stats_device_bytes() // 8, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    sptr = ctypes.c_void_p(stream.cuda_stream)
+
+    def step(ev0=None, ev1=None):
+        if ev0 is not None:
+            ev0.record(stream)
+        _native.check(L.rm_render_device(ctypes.byref(desc), ctypes.c_void_p(d_depth.data_ptr()),
+                                         ctypes.c_void_p(d_iters.data_ptr()), ctypes.c_void_p(d_hit.data_ptr()),
+                                         ctypes.c_void_p(d_stats.data_ptr()), sptr))
+        if ev1 is not None:
+            ev1.record(stream)
+        if plan is not None and world > 1:
+            # the frame's only exchange: RCCL all-gather of the three maps (xGMI), on the same stream
+            return [sharding.all_gather_frame(t, plan) for t in (d_depth, d_iters, d_hit)]
+        return None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(*evs[i])
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    st = _native.RmStats()
+    _native.check(L.rm_read_stats(ctypes.c_void_p(d_stats.data_ptr()), sptr, ctypes.byref(st)))
+    kernel_ms = [a.elapsed_time(b) for a, b in evs]
+    local = torch.tensor([elapsed, float(st.total_rays), float(st.sum_iters), sum(kernel_ms) / len(kernel_ms)],
+                         dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = local.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = local.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed_max, rays_step, iters_step, kms = float(mx[0]), float(sm[1]), float(sm[2]), float(mx[3])
+    else:
+        elapsed_max, rays_step, iters_step, kms = elapsed, float(st.total_rays), float(st.sum_iters), local[3].item()
+
+    if rank == 0:
+        total_rays = rays_step * args.steps
+        value = total_rays / elapsed_max / 1e6
+        rays_per_launch = float(st.total_rays)
+        achieved = BYTES_PER_RAY * rays_per_launch / (kms * 1e-3) / 1e9
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_r01.json")
+        if os.path.exists(pmc_path) and args.workload == "mandelbulb-1080p":
+            try:
+                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        # fp64 work estimate: evaluations x ~1.76 fractal iterations x ~1100 flop
+        line = {
+            "metric": "Mrays/sec (mean iters/ray alongside), 1920x1080 Mandelbulb/Standard" if not wl["sharded"]
+                      else f"Mrays/sec, {W}x{H} {scene.name}/Standard row-sharded",
+            "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if wl["sharded"] else "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "mean_iters_per_ray": iters_step / max(rays_step, 1.0),
+            "config": {"workload": f"{scene.name}/{wl['strategy']} {W}x{H}, MarchConfig(512, 1e-4, 100.0), "
+                                   f"camera {scene.camera_position or (0.0, 0.0, 5.0)}",
+                       "frames_per_step": 1 if wl["sharded"] else world,
+                       "rays_per_step": int(rays_step),
+                       "parallelism": (f"rowshard{world}-bandcyclic4+allgather" if wl["sharded"] else f"frame-per-gpu x{world}")},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel_ms_avg": kms, "bytes_per_ray": BYTES_PER_RAY,
+                         "note": "write-only path, 9 B/ray; the kernel is fp64-VALU / ray-latency bound (DESIGN.md)"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                line["cpu_baseline"] = cpu_baseline(scene.id, strat_id, cam, W, H, lip)
+            except Exception as e:  # the oracle is a checker; a failure here must not hide the GPU number
+                line["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port",
+                                        "sample": f"unavailable: {e}"}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

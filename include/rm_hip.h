@@ -60,7 +60,13 @@ typedef struct RmFrameDesc {
     int32_t tile_rows;   /* 0 = default (4); 4 or 8: rows per 64-pixel-wide wave tile */
     int32_t refill_min;  /* 0 = default; idle lanes required before a wave refills */
     int32_t grid_waves;  /* 0 = default (fill the device); persistent wavefront count */
-    int32_t reserved;
+    /* Band-cyclic row sharding (multi-GPU load balance): local row y of this slice is image row
+     *   row0 + ((y / band_rows) * band_stride + band_offset) * band_rows + y % band_rows.
+     * band_rows = 0 (or band_stride <= 1) means contiguous rows.  band_rows must be a multiple of
+     * the tile height; `rows` counts LOCAL rows and the mapped rows must stay below `height`. */
+    int32_t band_rows;
+    int32_t band_stride;
+    int32_t band_offset;
 } RmFrameDesc;
 
 /* Frame reduce computed in-kernel (the integer part of RayMarchStats.compute, core/types.py:77-137). */

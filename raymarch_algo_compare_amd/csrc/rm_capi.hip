@@ -99,10 +99,22 @@ int check_desc(const RmFrameDesc* d)
     if (d->scene_id < 0 || d->scene_id >= RM_NUM_SCENES) return fail(RM_E_BAD_SCENE, "scene_id %d out of range", d->scene_id);
     if (d->strategy_id < 0 || d->strategy_id >= RM_NUM_STRATEGIES)
         return fail(RM_E_BAD_STRATEGY, "strategy_id %d out of range", d->strategy_id);
-    if (d->width <= 0 || d->height <= 0 || d->row0 < 0 || d->rows < 0 || d->row0 + d->rows > d->height)
+    if (d->width <= 0 || d->height <= 0 || d->row0 < 0 || d->rows < 0 ||
+        (!(d->band_rows > 0 && d->band_stride > 1) && d->row0 + d->rows > d->height))
         return fail(RM_E_BAD_DIMS, "bad frame slice: %dx%d rows [%d,%d)", d->width, d->height, d->row0, d->row0 + d->rows);
     if ((long long)d->width * d->height > (1ll << 31) - 1) return fail(RM_E_BAD_DIMS, "frame too large");
     if (d->tile_rows != 0 && d->tile_rows != 4 && d->tile_rows != 8) return fail(RM_E_BAD_ARG, "tile_rows must be 0, 4 or 8");
+    if (d->band_rows < 0 || d->band_stride < 0 || d->band_offset < 0) return fail(RM_E_BAD_ARG, "negative band parameter");
+    if (d->band_rows > 0 && d->band_stride > 1) {
+        const int th = d->tile_rows ? d->tile_rows : 4;
+        if (d->band_rows % th) return fail(RM_E_BAD_ARG, "band_rows must be a multiple of the tile height %d", th);
+        if (d->band_offset >= d->band_stride) return fail(RM_E_BAD_ARG, "band_offset must be < band_stride");
+        if (d->rows > 0) {
+            const long long y = d->rows - 1;
+            const long long last = d->row0 + ((y / d->band_rows) * d->band_stride + d->band_offset) * d->band_rows + y % d->band_rows;
+            if (last >= d->height) return fail(RM_E_BAD_DIMS, "band-cyclic slice maps row %lld beyond height %d", last, d->height);
+        }
+    }
     return RM_OK;
 }
 
@@ -130,6 +142,9 @@ int make_args(const RmFrameDesc* d, float* depth, int32_t* iters, uint8_t* hit, 
     a->tiles_y = (d->rows + th - 1) / th;
     a->refill_min = d->refill_min > 0 ? d->refill_min : 24;
     a->hist_bins = rm::kHistBins;
+    if (d->band_rows > 0 && d->band_stride > 1) {
+        a->band_rows = d->band_rows; a->band_stride = d->band_stride; a->band_offset = d->band_offset;
+    }
     a->depth = depth; a->iters = iters; a->hit = hit; a->t_raw = traw; a->final_sdf = fs;
     a->block_var = bvar; a->stats = stats;
     *tile_h = th;

@@ -44,7 +44,8 @@ struct KernelArgs {
     int32_t width, height, row0, rows;
     int32_t tiles_x, tiles_y;
     int32_t refill_min;
-    int32_t hist_bins;        // clamp for the LDS histogram (<= kHistBins)
+    int32_t hist_bins;
+    int32_t band_rows, band_stride, band_offset;   // band-cyclic row map (band_rows == 0: identity)        // clamp for the LDS histogram (<= kHistBins)
     float* depth;             // rows*width, t if hit else 0 (types.py:93), fp32
     int32_t* iters;           // rows*width
     uint8_t* hit;             // rows*width
@@ -103,6 +104,10 @@ __global__ __launch_bounds__(64) void render_kernel(const KernelArgs a)
         // pixels of this tile that exist in the frame slice
         const int tw = min(kTileW, a.width - x0);
         const int th = min(TILE_H, a.rows - y0);
+        // image row of the tile's first row (tiles never straddle a band)
+        const int gy0 = a.band_rows > 0
+            ? a.row0 + ((y0 / a.band_rows) * a.band_stride + a.band_offset) * a.band_rows + (y0 % a.band_rows)
+            : a.row0 + y0;
 
         int pool_next = 0;            // wave-uniform: next unassigned tile-local pixel id
         bool active = false;
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(64) void render_kernel(const KernelArgs a)
                     if (id < TILE_PIX && px < tw && py < th) {
                         my_pix = py * kTileW + px;
                         vec3 o_unused;
-                        camera_ray(a.cam, a.width, a.height, x0 + px, a.row0 + y0 + py, o_unused, dir);
+                        camera_ray(a.cam, a.width, a.height, x0 + px, gy0 + py, o_unused, dir);
                         active = true;
                         if (s.start(cfg)) {
                             active = false;
@@ -184,8 +189,7 @@ __global__ __launch_bounds__(64) void render_kernel(const KernelArgs a)
                 S += __shfl_xor(S, 2); Q += __shfl_xor(Q, 2);
                 S += __shfl_xor(S, 4); Q += __shfl_xor(Q, 4);
                 const int brow = y0 + (r - 3);              // first row of this block, relative to row0
-                if (a.block_var && (lane & 7) == 0 && gx + 8 <= a.width && brow + 4 <= a.rows &&
-                    a.row0 + brow + 4 <= a.height) {
+                if (a.block_var && (lane & 7) == 0 && gx + 8 <= a.width && brow + 4 <= a.rows) {
                     // full blocks only (types.py:128-131)
                     a.block_var[(size_t)(brow >> 2) * (size_t)(a.width >> 3) + (size_t)(gx >> 3)] = 32 * Q - S * S;
                 }

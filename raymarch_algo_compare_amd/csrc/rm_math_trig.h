@@ -1,18 +1,202 @@
-// rm_math_trig.h -- sin, cos, acos, atan2, log of the path (catalog.py:277-293, :510-513).
+// rm_math_trig.h -- sin, cos, log (and acos / atan2, rm_math_atan.h) of the path
+// (catalog.py:277-293 Mandelbulb, :510-513 Gyroid), restating glibc 2.35.
 //
-// STATUS: PLATFORM (not yet exact).  These forward to the device math library
-// (OCML) in the HIP build and to libm in the host check build; both are < 1 ulp
-// but not bit-identical to glibc's, so rays that amplify ulp noise (Mandelbulb
-// boundary crawlers) may differ from the reference.  Only Mandelbulb (graded) and
-// Gyroid (next) reach these.  Exact restatements replace them one by one.
+// sin / cos: glibc sysdeps/ieee754/dbl-64/s_sin.c (IBM Accurate Mathematical Library,
+// after the 2.28 removal of the slow paths): table-driven do_sin / do_cos on
+// __sincostab (x = k/128), TAYLOR_SIN below 0.126, 4-part Cody-Waite reduction
+// (reduce_sincos) up to |x| < 105414350.  log: sysdeps/ieee754/dbl-64/e_log.c (ARM
+// optimized-routines).  As with pow, the x86-64 FMA multiarch build is what CPython
+// reaches, so the exact fused/unfused operation sequence below was read from that
+// variant's machine code (gcc contracted a*b+c there; every rm_fma is one of its
+// vfmadd/vfnmadd/vfmsub instructions, every plain * + - stays unfused).
+//
+// STATUS: rm_sin / rm_cos EXACT for |x| < 105414350 (the path needs |x| <= 8*pi for
+// Mandelbulb, <= ~320 for Gyroid); rm_log EXACT for positive finite x (normal or
+// subnormal).  Outside: platform fallback, not claimed exact.  Verified against libm
+// by tests/test_math_exact.py.
 #pragma once
 
 namespace rm {
 
-RM_MATH_HD double rm_sin(double x) { return ::sin(x); }
-RM_MATH_HD double rm_cos(double x) { return ::cos(x); }
-RM_MATH_HD double rm_acos(double x) { return ::acos(x); }
-RM_MATH_HD double rm_atan2(double y, double x) { return ::atan2(y, x); }
-RM_MATH_HD double rm_log(double x) { return ::log(x); }
+// ---- s_sin.c ----------------------------------------------------------------------
+
+struct SinCosK {
+    static constexpr double big = 0x1.8p45, toint = 0x1.8p52;
+    static constexpr double hpinv = 0x1.45f306dc9c883p-1;
+    static constexpr double hp0 = 0x1.921fb54442d18p+0, hp1 = 0x1.1a62633145c07p-54;
+    static constexpr double mp1 = 0x1.921fb58000000p+0, mp2 = -0x1.dde973c000000p-27;
+    static constexpr double pp3 = -0x1.cb3b398000000p-55, pp4 = -0x1.d747f23e32ed7p-83;
+    static constexpr double sn3 = -0x1.5555555555515p-3, sn5 = 0x1.11110e829872fp-7;
+    static constexpr double cs2 = 0.5, cs4 = -0x1.5555555555535p-5, cs6 = 0x1.6c16bedd9e239p-10;
+    static constexpr double s1 = -0x1.5555555555555p-3, s2 = 0x1.1111111110ecep-7, s3 = -0x1.a01a019db08b8p-13,
+                            s4 = 0x1.71de27b9a7ed9p-19, s5 = -0x1.addffc2fcdf59p-26;
+};
+
+RM_MATH_HD double rm_fnma(double a, double b, double c) { return rm_fma(-a, b, c); }   // -(a*b) + c, one rounding
+
+// TAYLOR_SIN(xx, x, dx): x + ((POLYNOMIAL(xx)*x - 0.5*dx)*xx + dx)
+RM_MATH_HD double rm_taylor_sin(double x, double dx)
+{
+    typedef SinCosK K;
+    double xx = x * x;
+    double p = rm_fma(xx, K::s5, K::s4);
+    p = rm_fma(xx, p, K::s3);
+    p = rm_fma(xx, p, K::s2);
+    p = rm_fma(xx, p, K::s1);
+    double q = rm_fma(p, x, -(dx * 0.5));
+    double t = rm_fma(xx, q, dx);
+    return x + t;
+}
+
+RM_MATH_HD double rm_do_sin(double x, double dx)
+{
+    typedef SinCosK K;
+    const double xold = x;
+    if (rm_fabs(x) < 0.126) return rm_taylor_sin(x, dx);
+    if (x <= 0.0) dx = -dx;
+    double u = K::big + rm_fabs(x);
+    x = rm_fabs(x) - (u - K::big);
+    int k = (int)(uint32_t)rm_asuint64(u) * 4;
+    double sn = rm_sincostab[k], ssn = rm_sincostab[k + 1], cs = rm_sincostab[k + 2], ccs = rm_sincostab[k + 3];
+    double xx = x * x;
+    double s = x + rm_fma(x * xx, rm_fma(xx, K::sn5, K::sn3), dx);
+    double c = rm_fma(x, dx, xx * rm_fma(xx, rm_fma(xx, K::cs6, K::cs4), K::cs2));
+    double cor = rm_fma(s, cs, rm_fnma(c, sn, rm_fma(s, ccs, ssn)));
+    return __builtin_copysign(sn + cor, xold);
+}
+
+RM_MATH_HD double rm_do_cos(double x, double dx)
+{
+    typedef SinCosK K;
+    if (x < 0.0) dx = -dx;
+    double u = K::big + rm_fabs(x);
+    x = (rm_fabs(x) - (u - K::big)) + dx;
+    int k = (int)(uint32_t)rm_asuint64(u) * 4;
+    double sn = rm_sincostab[k], ssn = rm_sincostab[k + 1], cs = rm_sincostab[k + 2], ccs = rm_sincostab[k + 3];
+    double xx = x * x;
+    double s = rm_fma(x * xx, rm_fma(xx, K::sn5, K::sn3), x);
+    double c = xx * rm_fma(xx, rm_fma(xx, K::cs6, K::cs4), K::cs2);
+    double cor = rm_fnma(s, sn, rm_fnma(c, cs, rm_fnma(s, ssn, ccs)));
+    return cs + cor;
+}
+
+// reduce_sincos: x -> (a, da) in [-pi/4, pi/4], returns the quadrant (low 2 bits meaningful)
+RM_MATH_HD int rm_reduce_sincos(double x, double* a, double* da)
+{
+    typedef SinCosK K;
+    double t = rm_fma(x, K::hpinv, K::toint);
+    double xn = t - K::toint;
+    int n = (int)(uint32_t)rm_asuint64(t);
+    double y = rm_fnma(xn, K::mp2, rm_fnma(xn, K::mp1, x));
+    double t2 = rm_fnma(xn, K::pp3, y);
+    double db = rm_fnma(K::pp3, xn, y - t2);
+    double b = rm_fnma(xn, K::pp4, t2);
+    db = db + rm_fnma(xn, K::pp4, t2 - b);
+    *a = b;
+    *da = db;
+    return n;
+}
+
+RM_MATH_HD double rm_do_sincos(double a, double da, int n)
+{
+    double r = (n & 1) ? rm_do_cos(a, da) : rm_do_sin(a, da);
+    return (n & 2) ? -r : r;
+}
+
+RM_MATH_HD double rm_sin(double x)
+{
+    typedef SinCosK K;
+    const uint32_t k = (uint32_t)(rm_asuint64(x) >> 32) & 0x7fffffffu;
+    if (k < 0x3e500000u) return x;                                  // |x| < 2^-26
+    if (k < 0x3feb6000u) return rm_do_sin(x, 0.0);                  // |x| < 0.855469
+    if (k < 0x400368fdu) {                                          // |x| < 2.426265
+        double t = K::hp0 - rm_fabs(x);
+        return __builtin_copysign(rm_do_cos(t, K::hp1), x);
+    }
+    if (k < 0x419921fbu) {                                          // |x| < 105414350
+        double a, da;
+        int n = rm_reduce_sincos(x, &a, &da);
+        return rm_do_sincos(a, da, n);
+    }
+    return ::sin(x);                                                // __branred range / inf / nan: unclaimed
+}
+
+RM_MATH_HD double rm_cos(double x)
+{
+    typedef SinCosK K;
+    const uint32_t k = (uint32_t)(rm_asuint64(x) >> 32) & 0x7fffffffu;
+    if (k < 0x3e400000u) return 1.0;                                // |x| < 2^-27
+    if (k < 0x3feb6000u) return rm_do_cos(x, 0.0);
+    if (k < 0x400368fdu) {
+        double y = K::hp0 - rm_fabs(x);
+        double a = y + K::hp1;
+        double da = (y - a) + K::hp1;
+        return rm_do_sin(a, da);
+    }
+    if (k < 0x419921fbu) {
+        double a, da;
+        int n = rm_reduce_sincos(x, &a, &da);
+        return rm_do_sincos(a, da, n + 1);
+    }
+    return ::cos(x);
+}
+
+// ---- e_log.c ------------------------------------------------------------------------
+
+RM_MATH_HD double rm_log(double x)
+{
+    const double Ln2hi = rm_log_head[0], Ln2lo = rm_log_head[1];
+    const double* A = rm_log_head + 2;    // poly[5]
+    const double* B = rm_log_head + 7;    // poly1[11]
+    uint64_t ix = rm_asuint64(x);
+    if (ix - 0x3fee000000000000ull < 0x3090000000000ull) {
+        // x is close to 1.0: log1p polynomial with a double-double leading term
+        if (ix == 0x3ff0000000000000ull) return 0.0;
+        double r = x - 1.0;
+        double r2 = r * r;
+        double r3 = r * r2;
+        double p1 = rm_fma(r2, B[3], rm_fma(r, B[2], B[1]));
+        double p2 = rm_fma(r2, B[6], rm_fma(r, B[5], B[4]));
+        double p3 = rm_fma(r3, B[10], rm_fma(r2, B[9], rm_fma(r, B[8], B[7])));
+        double y = rm_fma(rm_fma(p3, r3, p2), r3, p1);
+        double w = rm_fma(r, 0x1p27, r);
+        double rhi = rm_fnma(0x1p27, r, w);
+        double rlo = r - rhi;
+        double rhi2 = rhi * rhi;
+        double hi = rm_fma(rhi2, B[0], r);
+        double lo = rm_fma(rhi2, B[0], r - hi);
+        lo = rm_fma(B[0] * rlo, r + rhi, lo);
+        y = rm_fma(y, r3, lo);
+        return hi + y;
+    }
+    uint32_t top = (uint32_t)(ix >> 48);
+    if (top - 0x0010 >= 0x7ff0 - 0x0010) {
+        if (ix * 2 == 0) return -__builtin_inf();                  // log(+-0) = -inf
+        if (ix == 0x7ff0000000000000ull) return x;                 // log(inf) = inf
+        if ((top & 0x8000) || (top & 0x7ff0) == 0x7ff0) return (x - x) / (x - x);   // x < 0 or nan
+        ix = rm_asuint64(x * 0x1p52);                               // subnormal: normalise
+        ix -= 52ull << 52;
+    }
+    uint64_t tmp = ix - 0x3fe6000000000000ull;
+    int i = (int)((tmp >> 45) & 127);
+    int k = (int)((int64_t)tmp >> 52);
+    uint64_t iz = ix - (tmp & 0xfff0000000000000ull);
+    double invc = rm_log_tab[2 * i], logc = rm_log_tab[2 * i + 1];
+    double z = rm_asdouble(iz);
+    double r = rm_fma(z, invc, -1.0);
+    double kd = (double)k;
+    double w = rm_fma(kd, Ln2hi, logc);
+    double hi = w + r;
+    double lo = (w - hi) + r;
+    lo = rm_fma(kd, Ln2lo, lo);
+    double r2 = r * r;
+    double r3 = r * r2;
+    lo = rm_fma(r2, A[0], lo);
+    double q = rm_fma(rm_fma(r, A[4], A[3]), r2, rm_fma(r, A[2], A[1]));
+    double y = rm_fma(r3, q, lo);
+    return y + hi;
+}
 
 }  // namespace rm
+
+#include "rm_math_atan.h"

@@ -66,3 +66,18 @@ def hip():
     from raymarch_algo_compare_amd import _native
     _native.init()
     return _native
+
+
+def build_native(name: str) -> str:
+    """g++ build of a tests/native/*.cpp check harness (host compile of the product's kernel
+    headers, tests only).  Returns the path of the shared object."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "native", f"{name}.cpp")
+    out = os.path.join(ROOT, "tests", "native", f"_build_{name}.so")
+    hdr_dir = os.path.join(ROOT, "raymarch_algo_compare_amd", "csrc")
+    newest = max([os.path.getmtime(src)] + [os.path.getmtime(os.path.join(hdr_dir, f))
+                                            for f in os.listdir(hdr_dir) if f.endswith(".h")])
+    if not os.path.exists(out) or os.path.getmtime(out) < newest:
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-msse4.1",
+                        "-fno-builtin", "-o", out, src], check=True)
+    return out

@@ -1,0 +1,73 @@
+"""rm_math*.h against glibc's libm on the host (the library CPython reaches in the reference):
+functions marked EXACT in DESIGN.md must agree bit-for-bit on the argument ranges of the path
+(SURVEY.md Appendix C)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import build_native
+
+N = 400_000
+
+
+@pytest.fixture(scope="module")
+def m():
+    L = ctypes.CDLL(build_native("math_check"))
+    return L
+
+
+def _call2(L, name, x, y):
+    dp = ctypes.POINTER(ctypes.c_double)
+    out = np.empty_like(x)
+    getattr(L, name)(x.ctypes.data_as(dp), y.ctypes.data_as(dp), ctypes.c_size_t(len(x)), out.ctypes.data_as(dp))
+    return out
+
+
+def _call1(L, name, x):
+    dp = ctypes.POINTER(ctypes.c_double)
+    out = np.empty_like(x)
+    getattr(L, name)(x.ctypes.data_as(dp), ctypes.c_size_t(len(x)), out.ctypes.data_as(dp))
+    return out
+
+
+def _bits_equal(a, b):
+    return int((a.view(np.uint64) != b.view(np.uint64)).sum())
+
+
+@pytest.mark.parametrize("y", [0.5, 2.0, 7.0, 8.0])
+def test_pow_exact(m, y):
+    rng = np.random.default_rng(int(y * 10))
+    hi = 4.0 if y >= 7 else 1e6
+    sets = [rng.uniform(0, hi, N), np.exp(rng.uniform(-40 if y > 1 else -700, np.log(hi), N)), rng.uniform(0.99, 1.01, N)]
+    v = rng.uniform(-4, 4, (N, 3))
+    s = (v * v).sum(1)
+    sets.append(np.minimum(np.sqrt(s), 4.0) if y >= 7 else s)
+    sets.append(np.array([0.0, 1.0, np.inf, 5e-324, 1e-310, 2.2250738585072014e-308, 4.0, np.nan,
+                          1.0000000000000002, 0.9999999999999999]))
+    for x in sets:
+        yy = np.full(len(x), y)
+        assert _bits_equal(_call2(m, "rmc_pow", x, yy), _call2(m, "rml_pow", x, yy)) == 0
+
+
+def _ranges_sincos(rng):
+    return [rng.uniform(-8 * np.pi, 8 * np.pi, N), rng.uniform(-0.2, 0.2, N), rng.uniform(-3, 3, N),
+            rng.uniform(-400, 400, N), rng.uniform(-1e8, 1e8, N), np.exp(rng.uniform(-40, 3, N)) * rng.choice([-1, 1], N),
+            np.array([0.0, -0.0, 0.126, -0.126, 0.855469, 2.426265, np.pi, -np.pi, np.pi / 2, 1e-9, 105414349.0])]
+
+
+def test_sin_exact(m):
+    for x in _ranges_sincos(np.random.default_rng(3)):
+        assert _bits_equal(_call1(m, "rmc_sin", x), _call1(m, "rml_sin", x)) == 0
+
+
+def test_cos_exact(m):
+    for x in _ranges_sincos(np.random.default_rng(4)):
+        assert _bits_equal(_call1(m, "rmc_cos", x), _call1(m, "rml_cos", x)) == 0
+
+
+def test_log_exact(m):
+    rng = np.random.default_rng(5)
+    for x in [rng.uniform(1e-12, 7e4, N), np.exp(rng.uniform(-740, 700, N)), rng.uniform(0.9, 1.1, N),
+              rng.uniform(0.93, 1.07, N), np.array([1.0, 1e-12, 4.0, 5e-324, 1e-310, np.inf, 0.9375, 1.0644])]:
+        assert _bits_equal(_call1(m, "rmc_log", x), _call1(m, "rml_log", x)) == 0
