@@ -46,10 +46,11 @@ WORKLOADS = {
 
 def cpu_baseline(scene_id, strategy_id, cam14, width, height, lipschitz):
     """Oracle (CPU restatement of the reference, oracle/rm_oracle.c) on a bounded sample of the
-    same workload: all host threads on the middle 256 rows + one thread on 24 of them."""
+    same workload (about 10-30 s of CPU work): every host thread on the whole frame (capped at
+    1080 rows) + one thread on 24 centre rows."""
     from oracle import oracle
-    threads = max(1, min(os.cpu_count() or 1, 64))
-    rows_mt = min(height, 256)
+    threads = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 64))
+    rows_mt = min(height, 1080)
     r0 = (height - rows_mt) // 2
     t0 = time.perf_counter()
     fr = oracle.render(scene_id, strategy_id, cam14, width, height, row0=r0, rows=rows_mt, lipschitz=lipschitz,
@@ -123,8 +124,12 @@ def main():
     d_iters = torch.empty((rows_local, W), dtype=torch.int32, device=dev)
     d_hit = torch.empty((rows_local, W), dtype=torch.uint8, device=dev)
     d_stats = torch.zeros(L.rm_stats_device_bytes() // 8, dtype=torch.int64, device=dev)
-    stream = torch.cuda.current_stream(dev)
+    # a dedicated (non-default) torch stream: its handle is non-NULL, so the kernel, the bracketing
+    # events and the RCCL gather all sit on this one stream (NULL would mean "library stream")
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     sptr = ctypes.c_void_p(stream.cuda_stream)
+    assert sptr.value, "expected a non-default stream handle"
 
     def step(ev0=None, ev1=None):
         if ev0 is not None:

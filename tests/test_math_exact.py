@@ -71,3 +71,31 @@ def test_log_exact(m):
     for x in [rng.uniform(1e-12, 7e4, N), np.exp(rng.uniform(-740, 700, N)), rng.uniform(0.9, 1.1, N),
               rng.uniform(0.93, 1.07, N), np.array([1.0, 1e-12, 4.0, 5e-324, 1e-310, np.inf, 0.9375, 1.0644])]:
         assert _bits_equal(_call1(m, "rmc_log", x), _call1(m, "rml_log", x)) == 0
+
+
+def test_acos_exact(m):
+    rng = np.random.default_rng(6)
+    sets = [rng.uniform(-1, 1, N), rng.uniform(0.96, 1.0, N), -rng.uniform(0.96, 1.0, N), rng.uniform(-0.13, 0.13, N),
+            1.0 - np.exp(rng.uniform(-40, -3, N)), -1.0 + np.exp(rng.uniform(-40, -3, N)),
+            np.exp(rng.uniform(-60, 0, N)) * rng.choice([-1, 1], N),
+            np.array([0.0, -0.0, 1.0, -1.0, 0.125, 0.5, 0.75, 0.921875, 0.953125, 0.96875, -0.125, -0.5, -0.75,
+                      -0.921875, -0.953125, -0.96875, 0.25, -0.25, 1e-17, 2.7e-17, 0.9999999999999999])]
+    # z.z / r of unit-ish vectors, the actual call-site distribution (catalog.py:277)
+    v = rng.normal(size=(N, 3))
+    sets.append(np.clip(v[:, 2] / np.sqrt((v * v).sum(1)), -1, 1))
+    for x in sets:
+        assert _bits_equal(_call1(m, "rmc_acos", x), _call1(m, "rml_acos", x)) == 0
+
+
+def test_atan2_exact(m):
+    rng = np.random.default_rng(7)
+    pairs = [(rng.uniform(-4, 4, N), rng.uniform(-4, 4, N)),
+             (rng.normal(size=N), rng.normal(size=N)),
+             (np.exp(rng.uniform(-30, 30, N)) * rng.choice([-1, 1], N), np.exp(rng.uniform(-30, 30, N)) * rng.choice([-1, 1], N)),
+             (np.exp(rng.uniform(-700, 700, N)) * rng.choice([-1, 1], N), np.exp(rng.uniform(-700, 700, N)) * rng.choice([-1, 1], N)),
+             (rng.uniform(-1, 1, N) * 1e-3, rng.uniform(-4, 4, N)), (rng.uniform(-4, 4, N), rng.uniform(-1, 1, N) * 1e-3)]
+    sp = np.array([0.0, -0.0, 1.0, -1.0, 2.0, -2.0, 1e-300, -1e-300, 1e300, 0.0625, 16.0])
+    yy, xx = np.meshgrid(sp, sp)
+    pairs.append((yy.ravel().copy(), xx.ravel().copy()))
+    for y, x in pairs:
+        assert _bits_equal(_call2(m, "rmc_atan2", y, x), _call2(m, "rml_atan2", y, x)) == 0

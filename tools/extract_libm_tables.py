@@ -20,12 +20,18 @@ def d2b(x: float) -> bytes:
     return struct.pack("<d", x)
 
 
-def find(blob: bytes, anchor: bytes, what: str) -> int:
+def find(blob: bytes, anchor: bytes, what: str, nbytes: int = 0) -> int:
+    """Offset of the table starting with `anchor`.  Static tables are emitted once per multiarch
+    variant (sse2 / fma / fma4); several hits are accepted when all copies are byte-identical
+    over the `nbytes` that will be read."""
     i = blob.find(anchor)
     if i < 0:
         sys.exit(f"anchor for {what} not found")
-    if blob.find(anchor, i + 1) >= 0:
-        sys.exit(f"anchor for {what} is ambiguous")
+    j = blob.find(anchor, i + 1)
+    while j >= 0:
+        if not nbytes or blob[j:j + nbytes] != blob[i:i + nbytes]:
+            sys.exit(f"anchor for {what} is ambiguous")
+        j = blob.find(anchor, j + 1)
     return i
 
 
@@ -95,6 +101,25 @@ def main():
     assert abs(tab[4 * 64] - math.sin(0.5)) < 1e-15 and abs(tab[4 * 64 + 2] - math.cos(0.5)) < 1e-15
     parts.append("// __sincostab (sysdeps/ieee754/dbl-64/sincostab.c): {sn, ssn, cs, ccs} for x = k/128, k = 0..109\n"
                  "RM_TAB double rm_sincostab[440] = {\n" + fmt_d(tab, 4) + "\n};\n")
+
+    # asncs (sysdeps/ieee754/dbl-64/asincos.tbl): 2568 doubles of per-interval centre points,
+    # polynomial coefficients and asin values (rows of 11 / 12 / 13 / 14 / 15 doubles)
+    def anchor_hex(*hx):
+        return b"".join(d2b(float.fromhex(h)) for h in hx)
+    off = find(blob, anchor_hex("0x1.0400000000000p-3", "0x1.0216988994424p+0", "0x1.0a6a2b799b115p-4"), "asncs", 2568 * 8)
+    tab = doubles(blob, off, 2568)
+    parts.append("// asncs (sysdeps/ieee754/dbl-64/asincos.tbl)\n"
+                 "RM_TAB double rm_asncs[2568] = {\n" + fmt_d(tab, 4) + "\n};\n")
+    # inroot (sysdeps/ieee754/dbl-64/root.tbl): 1/sqrt seeds
+    off = find(blob, anchor_hex("0x1.68a1f80d71820p+0", "0x1.65de82af9631fp+0", "0x1.632b1201d39e5p+0"), "inroot", 128 * 8)
+    tab = doubles(blob, off, 128)
+    parts.append("// inroot (sysdeps/ieee754/dbl-64/root.tbl)\n"
+                 "RM_TAB double rm_inroot[128] = {\n" + fmt_d(tab, 4) + "\n};\n")
+    # cij (sysdeps/ieee754/dbl-64/uatan.tbl): 241 rows {x_i, atan(x_i), c1..c5}
+    off = find(blob, anchor_hex("0x1.0400665e0244ep-4", "0x1.03a737b53dd20p-4", "0x1.fdf1fcf5cfb72p-1"), "cij", 241 * 7 * 8)
+    tab = doubles(blob, off, 241 * 7)
+    parts.append("// cij (sysdeps/ieee754/dbl-64/uatan.tbl): 241 x 7\n"
+                 "RM_TAB double rm_cij[1687] = {\n" + fmt_d(tab, 7) + "\n};\n")
 
     with open(OUT, "w") as f:
         f.write("// GENERATED by tools/extract_libm_tables.py from the system libm.so.6\n"
