@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Developer experiments on a GPU box (not product, not tests): where does Mandelbulb/Standard
+1080p spend its time?  Usage: python tools/dev_exp.py <exp> ..."""
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from raymarch_algo_compare_amd import _native, registry
+from raymarch_algo_compare_amd.camera import Camera
+
+def cam_for(scene, W, H):
+    return Camera(scene.camera_position or (0.0, 0.0, 5.0), scene.camera_target or (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 60.0, W, H)
+
+def run(sid, kid, W=1920, H=1080, repeats=5, warmup=2, max_iterations=512, **tuning):
+    scene = registry.SCENES[sid]
+    desc = _native.make_desc(sid, kid, cam_for(scene, W, H).params14(), W, H, max_iterations=max_iterations, **tuning)
+    out = _native.render(desc, warmup=warmup, repeats=repeats)
+    st = out["stats"]
+    r = dict(scene=scene.name, strat=registry.list_strategies()[kid], WxH=f"{W}x{H}", maxit=max_iterations,
+             ms=round(out["timing"]["ms_median"], 4), ms_min=round(out["timing"]["ms_min"], 4),
+             mrays=round(W * H / out["timing"]["ms_median"] / 1e3, 1),
+             mean_iters=round(st["sum_iters"] / max(st["total_rays"], 1), 3), max_it=st["iter_max"], **tuning)
+    print(json.dumps(r), flush=True)
+    return r
+
+exp = sys.argv[1] if len(sys.argv) > 1 else "budget"
+if exp == "budget":
+    for mi in (16, 32, 64, 128, 256, 512):
+        run(10, 0, max_iterations=mi)
+    for gw in (256, 512, 1024, 2048, 4096):
+        run(10, 0, grid_waves=gw)
+    for gw in (512, 1024, 2048):
+        run(10, 0, grid_waves=gw, refill_min=8)
+    for W, H in ((960, 540), (3840, 2160), (7680, 4320)):
+        run(10, 0, W=W, H=H, repeats=3, warmup=1)
+elif exp == "one":
+    run(int(sys.argv[2]), int(sys.argv[3]), repeats=int(sys.argv[4]) if len(sys.argv) > 4 else 5)
+elif exp == "matrix":
+    for sid in range(14):
+        for key in registry.GRADED_STRATEGY_KEYS:
+            run(sid, registry.STRATEGIES[key], repeats=3, warmup=1)
