@@ -1,0 +1,70 @@
+"""The C-ABI library loads without a GPU, exports every symbol include/rm_hip.h declares, its
+structs have the layout the ctypes binding assumes, and it fails loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+from conftest import ROOT
+from raymarch_algo_compare_amd import _native
+
+
+def _header():
+    return open(os.path.join(ROOT, "include", "rm_hip.h"), encoding="utf-8").read()
+
+
+def test_every_declared_symbol_is_exported():
+    declared = set(re.findall(r"^(?:int|void|size_t|const char\*)\s+(rm_\w+)\(", _header(), flags=re.M))
+    assert declared and declared == set(_native.EXPORTS)
+    lib = _native.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_struct_layout_matches_header():
+    src = '#include <stdio.h>\n#include "rm_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu\\n", sizeof(RmMarchConfig),' \
+          'sizeof(RmFrameDesc), sizeof(RmStats), sizeof(RmTiming), sizeof(RmDeviceInfo)); return 0;}\n'
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "s.c")
+        open(c, "w").write(src)
+        exe = os.path.join(td, "s")
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
+        sizes = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
+    assert sizes == [ctypes.sizeof(_native.RmMarchConfig), ctypes.sizeof(_native.RmFrameDesc),
+                     ctypes.sizeof(_native.RmStats), ctypes.sizeof(_native.RmTiming), ctypes.sizeof(_native.RmDeviceInfo)]
+
+
+def test_registry_sizes():
+    lib = _native.load()
+    assert lib.rm_num_scenes() == 20 and lib.rm_num_strategies() == 11
+    assert lib.rm_stats_device_bytes() == 8 * (8 + _native.RM_HIST_BINS)
+
+
+def test_no_cpu_fallback_without_device():
+    """Without rm_init on a gfx950 device every compute entry point reports RM_E_NO_DEVICE."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; the no-device behaviour is checked on CPU-only hosts")
+    lib = _native.load()
+    assert lib.rm_init(0) == -4
+    d = _native.make_desc(0, 0, [0.0] * 14, 8, 8)
+    assert lib.rm_render(ctypes.byref(d), None, None, None, None, None, None, None, None) == -4
+    assert b"rm_init" in lib.rm_last_error()
+    with pytest.raises(_native.RmError):
+        _native.init(0)
+    from raymarch_algo_compare_amd import run_once
+    with pytest.raises(_native.RmError):
+        run_once()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "raymarch_algo_compare_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                text = open(os.path.join(dp, f), encoding="utf-8", errors="replace").read()
+                for needle in ("import oracle", "from oracle", "oracle/", "oracle.render", "oracle.lib", "librm_oracle", "rmo_", "_build_host_check", "_build_math_check"):
+                    assert needle not in text, (os.path.join(dp, f), needle)
