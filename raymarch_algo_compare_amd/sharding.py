@@ -74,7 +74,7 @@ def assemble(parts, plans) -> np.ndarray:
 def all_gather_frame(local, plan: ShardPlan, group=None):
     """RCCL (backend 'nccl') / gloo all-gather of one output map and un-permutation into image
     order.  `local` is a torch tensor (rows, W) on this rank's device; returns (H, W) on every rank.
-    Equal shard sizes are required (cyclic plans always satisfy that)."""
+    Cyclic plans have equal shards; uneven contiguous plans are padded for the collective."""
     import torch
     import torch.distributed as dist
     N = plan.world_size
@@ -83,10 +83,15 @@ def all_gather_frame(local, plan: ShardPlan, group=None):
     if not plan.cyclic:
         sizes = [plan_rows(plan.height, N, r).rows for r in range(N)]
         if len(set(sizes)) != 1:
-            parts = [torch.empty((s, local.shape[1]), dtype=local.dtype, device=local.device) for s in sizes]
-            dist.all_gather(parts, local.contiguous(), group=group)
-            return torch.cat(parts, dim=0)
-    gathered = torch.empty((N,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+            # uneven contiguous blocks: pad every shard to the largest, gather, trim
+            mx, W = max(sizes), local.shape[1]
+            padded = torch.zeros((mx, W), dtype=local.dtype, device=local.device)
+            padded[: local.shape[0]] = local
+            buf = torch.empty((N * mx, W), dtype=local.dtype, device=local.device)
+            dist.all_gather_into_tensor(buf, padded, group=group)
+            return torch.cat([buf[r * mx: r * mx + sizes[r]] for r in range(N)], dim=0)
+    # output laid out as the concatenation of the rank shards along dim 0 (the form every backend accepts)
+    gathered = torch.empty((N * local.shape[0], local.shape[1]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(gathered, local.contiguous(), group=group)
     if not plan.cyclic:
         return gathered.reshape(plan.height, local.shape[1])
