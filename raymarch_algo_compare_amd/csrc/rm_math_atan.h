@@ -9,9 +9,9 @@
 // 241-row cij table, four quadrant cases.
 // Operation order and the fused operations are those of the x86-64 FMA variants' machine code.
 //
-// STATUS: rm_acos EXACT on [-1, 1]; rm_atan2 EXACT for finite arguments whose exponents differ
-// by < 57*2^20 ... i.e. every finite pair (the huge-ratio shortcuts are included), zeros included.
-// NaN / infinity arguments take the platform fallback (not reachable from the path).
+// STATUS: rm_acos EXACT on [-1, 1] (NaN outside); rm_atan2 EXACT for every finite pair, zeros and
+// the huge-ratio shortcuts included.  NaN / infinity arguments of atan2 take the platform fallback
+// (not reachable from the path).
 #pragma once
 
 namespace rm {
@@ -29,28 +29,39 @@ struct AtanK {
 };
 
 // ---- e_asin.c: __ieee754_acos -----------------------------------------------------------
+//
+// Branch-free over the common bands: the Taylor band (|x| < 1/8) and ONE unified table band are
+// always evaluated and selected.  The five table bands of e_asin.c differ only in row stride and
+// polynomial degree (5..9); a band of degree D is evaluated here as a degree-9 Horner chain whose
+// leading coefficients are +0 -- fma(xx, +0, c) == c exactly, so the value is bit-identical to the
+// shorter chain.  Only the 1/sqrt band (|x| >= 0.96875, ~3 % of arguments) stays a branch.
 
-// one table band: row at asncs[n], polynomial degree DEG in xx = |x| - centre
-template <int DEG>
-RM_MATH_HD double rm_acos_band(double x, int m, int n)
+RM_MATH_HD double rm_acos_sqrt_band(double x, int m)          // 0.96875 <= |x| < 1
 {
     typedef AtanK K;
-    const double* a = rm_asncs + n;
-    double xx = ((m > 0) ? x : -x) - a[0];
-    double p = a[DEG + 1];
-#pragma unroll
-    for (int j = DEG; j >= 2; --j) p = rm_fma(xx, p, a[j]);
-    p = rm_fma(xx * xx, p, a[DEG + 2]);
-    double t = rm_fma(xx, a[1], p);
-    double c = a[DEG + 3];
-    if (m > 0) {
-        double y = K::hpi - c;
-        t = K::hpi1 - t;
-        return t + y;
-    }
-    double y = c + K::hpi;
-    t = t + K::hpi1;
-    return t + y;
+    double z = ((m > 0) ? (1.0 - x) : (x + 1.0)) * 0.5;
+    const int kz = (int)(rm_asuint64(z) >> 32);
+    double t = rm_inroot[(kz >> 14) & 0x7f] * rm_asdouble((uint64_t)(1023 + (511 - (kz >> 21))) << 52);  // powtwo[]
+    double r = rm_fnma(t * t, z, 1.0);
+    double q = rm_fma(r, K::rt3, K::rt2);
+    q = rm_fma(r, q, K::rt1);
+    q = rm_fma(r, q, K::rt0);
+    t = q * t;
+    double c = z * t;
+    double h = rm_fnma(c, t * 0.5, 1.5);
+    double y = rm_fnma(K::t27, c, rm_fma(c, K::t27, c));
+    double ty = rm_fma(h, c, y);                             // t + y with t = c*(1.5 - 0.5*t*c)
+    double cc = rm_fnma(y, y, z) / ty;
+    double p = rm_fma(z, K::f6, K::f5);
+    p = rm_fma(z, p, K::f4);
+    p = rm_fma(z, p, K::f3);
+    p = rm_fma(z, p, K::f2);
+    p = rm_fma(z, p, K::f1);
+    double pz = (p * z) * (y + cc);
+    double res_neg = ((K::hpi1 - cc) - pz) + (K::hpi - y);
+    double res_pos = (cc + pz) + y;
+    double res = (m < 0) ? res_neg : res_pos;
+    return res + res;
 }
 
 RM_MATH_HD double rm_acos(double x)
@@ -59,62 +70,64 @@ RM_MATH_HD double rm_acos(double x)
     const uint64_t bits = rm_asuint64(x);
     const int m = (int)(bits >> 32);
     const int k = m & 0x7fffffff;
-    if (k < 0x3c880000) return K::hpi;                           // |x| < 2^-55
-    if (k < 0x3fc00000) {                                        // |x| < 1/8
-        double x2 = x * x;
-        double p = rm_fma(x2, K::f6, K::f5);
-        p = rm_fma(x2, p, K::f4);
-        p = rm_fma(x2, p, K::f3);
-        p = rm_fma(x2, p, K::f2);
-        p = rm_fma(x2, p, K::f1);
-        double r = K::hpi - x;
-        double cor = rm_fnma(p, x * x2, ((K::hpi - r) - x) + K::hpi1);
-        return r + cor;
+    const bool pos = m > 0;
+    const double ax = rm_fabs(x);
+
+    // |x| < 1/8: Taylor
+    const double x2 = x * x;
+    double pt = rm_fma(x2, K::f6, K::f5);
+    pt = rm_fma(x2, pt, K::f4);
+    pt = rm_fma(x2, pt, K::f3);
+    pt = rm_fma(x2, pt, K::f2);
+    pt = rm_fma(x2, pt, K::f1);
+    const double rt = K::hpi - x;
+    const double res_taylor = rt + rm_fnma(pt, x * x2, ((K::hpi - rt) - x) + K::hpi1);
+
+    // 1/8 <= |x| < 0.96875: unified table band
+    const int i13 = (k >> 13) & 0x7f;
+    int n = 11 * ((k >> 15) & 0x1f), deg = 5;
+    n = (k >= 0x3fd00000) ? 11 * ((k >> 14) & 0x3f) + 352 : n;
+    n = (k >= 0x3fe00000) ? 1056 + 12 * i13 : n;  deg = (k >= 0x3fe00000) ? 6 : deg;
+    n = (k >= 0x3fe80000) ? 992 + 13 * i13 : n;   deg = (k >= 0x3fe80000) ? 7 : deg;
+    n = (k >= 0x3fed8000) ? 884 + 14 * i13 : n;   deg = (k >= 0x3fed8000) ? 8 : deg;
+    n = (k >= 0x3fee8000) ? 768 + 15 * i13 : n;   deg = (k >= 0x3fee8000) ? 9 : deg;
+    n = (n > 2568 - 13) ? 2568 - 13 : n;          // keeps the gather in bounds for out-of-band arguments
+    const double* a = rm_asncs + n;
+    const double xx = ax - a[0];
+    double p = (deg >= 9) ? a[10] : 0.0;
+    p = rm_fma(xx, p, (deg >= 8) ? a[9] : 0.0);
+    p = rm_fma(xx, p, (deg >= 7) ? a[8] : 0.0);
+    p = rm_fma(xx, p, (deg >= 6) ? a[7] : 0.0);
+    p = rm_fma(xx, p, a[6]);
+    p = rm_fma(xx, p, a[5]);
+    p = rm_fma(xx, p, a[4]);
+    p = rm_fma(xx, p, a[3]);
+    p = rm_fma(xx, p, a[2]);
+    const double c0 = (deg == 5) ? a[7] : (deg == 6) ? a[8] : (deg == 7) ? a[9] : (deg == 8) ? a[10] : a[11];
+    const double cv = (deg == 5) ? a[8] : (deg == 6) ? a[9] : (deg == 7) ? a[10] : (deg == 8) ? a[11] : a[12];
+    p = rm_fma(xx * xx, p, c0);
+    const double t = rm_fma(xx, a[1], p);
+    const double yb = pos ? (K::hpi - cv) : (cv + K::hpi);
+    const double tb = pos ? (K::hpi1 - t) : (t + K::hpi1);
+    const double res_band = tb + yb;
+
+    double res = (k < 0x3fc00000) ? res_taylor : res_band;
+    res = (k < 0x3c880000) ? K::hpi : res;                        // |x| < 2^-55
+    if (__builtin_expect(k >= 0x3fef0000, 0)) {                   // rare tail: |x| >= 0.96875
+        if (k < 0x3ff00000) return rm_acos_sqrt_band(x, m);
+        if (k == 0x3ff00000 && (uint32_t)bits == 0) return pos ? 0.0 : K::opi;   // |x| == 1
+        return __builtin_nan("");                                 // |x| > 1 or NaN: invalid
     }
-    if (k < 0x3fe00000) {                                        // 1/8 <= |x| < 1/2
-        int n = (k < 0x3fd00000) ? 11 * ((k >> 15) & 0x1f) : 11 * ((k >> 14) & 0x3f) + 352;
-        return rm_acos_band<5>(x, m, n);
-    }
-    if (k < 0x3fe80000) return rm_acos_band<6>(x, m, 1056 + 12 * ((k >> 13) & 0x7f));   // < 0.75
-    if (k < 0x3fed8000) return rm_acos_band<7>(x, m, 992 + 13 * ((k >> 13) & 0x7f));     // < 0.921875
-    if (k < 0x3fee8000) return rm_acos_band<8>(x, m, 884 + 14 * ((k >> 13) & 0x7f));     // < 0.953125
-    if (k < 0x3fef0000) return rm_acos_band<9>(x, m, 768 + 15 * ((k >> 13) & 0x7f));     // < 0.96875
-    if (k < 0x3ff00000) {                                        // 0.96875 <= |x| < 1
-        double z = ((m > 0) ? (1.0 - x) : (x + 1.0)) * 0.5;
-        const uint64_t zb = rm_asuint64(z);
-        const int kz = (int)(zb >> 32);
-        double t = rm_inroot[(kz >> 14) & 0x7f] * rm_asdouble((uint64_t)(1023 + (511 - (kz >> 21))) << 52);  // powtwo[]
-        double r = rm_fnma(t * t, z, 1.0);
-        double q = rm_fma(r, K::rt3, K::rt2);
-        q = rm_fma(r, q, K::rt1);
-        q = rm_fma(r, q, K::rt0);
-        t = q * t;
-        double c = z * t;
-        double h = rm_fnma(c, t * 0.5, 1.5);
-        double y = rm_fnma(K::t27, c, rm_fma(c, K::t27, c));
-        double ty = rm_fma(h, c, y);                             // t + y with t = c*(1.5 - 0.5*t*c)
-        double cc = rm_fnma(y, y, z) / ty;
-        double p = rm_fma(z, K::f6, K::f5);
-        p = rm_fma(z, p, K::f4);
-        p = rm_fma(z, p, K::f3);
-        p = rm_fma(z, p, K::f2);
-        p = rm_fma(z, p, K::f1);
-        double pz = (p * z) * (y + cc);
-        if (m < 0) {
-            double cor = (K::hpi1 - cc) - pz;
-            double res1 = K::hpi - y;
-            double res = cor + res1;
-            return res + res;
-        }
-        double res = (cc + pz) + y;
-        return res + res;
-    }
-    if (k == 0x3ff00000 && (uint32_t)bits == 0) return (m > 0) ? 0.0 : K::opi;   // |x| == 1
-    if (x != x) return x + x;
-    return (x - x) / (x - x);                                    // |x| > 1: invalid
+    return res;
 }
 
 // ---- e_atan2.c: __ieee754_atan2 ------------------------------------------------------------
+//
+// Branch-free main path: the quotient u = min/max as a double-double, then the degree-13 series
+// (u < 1/16) and the cij-table form are both evaluated for the two structural cases -- (i) x > 0,
+// |y| < |x| and the three "pi/2 or pi plus/minus atan" cases, which differ only in a base constant
+// and a sign (a - b == a + (-b) bit-for-bit) -- and one result is selected.  Zeros, infinities,
+// NaNs and exponent gaps >= 57 take a rare out-of-line branch.
 
 RM_MATH_HD double rm_atan_series(double v)   // d3 + v*(d5 + v*(d7 + v*(d9 + v*(d11 + v*d13))))
 {
@@ -126,124 +139,85 @@ RM_MATH_HD double rm_atan_series(double v)   // d3 + v*(d5 + v*(d7 + v*(d9 + v*(
     return rm_fma(v, p, K::d3);
 }
 
-RM_MATH_HD const double* rm_atan_row(double u)
+RM_MATH_HD double rm_atan2_special(double y, double x)
 {
-    int i = (int)(rm_fma(u, 256.0, 0x1p52) - 0x1p52) - 16;
-    return rm_cij + 7 * i;
-}
-
-RM_MATH_HD double rm_atan_row_poly(const double* c, double v)   // c2 + v*(c3 + v*(c4 + v*(c5 + v*c6)))
-{
-    double p = rm_fma(v, c[6], c[5]);
-    p = rm_fma(v, p, c[4]);
-    p = rm_fma(v, p, c[3]);
-    return rm_fma(v, p, c[2]);
+    typedef AtanK K;
+    const uint64_t bx = rm_asuint64(x), by = rm_asuint64(y);
+    const uint32_t ux = (uint32_t)(bx >> 32), uy = (uint32_t)(by >> 32);
+    if ((ux & 0x7ff00000u) == 0x7ff00000u || (uy & 0x7ff00000u) == 0x7ff00000u) return ::atan2(y, x);   // inf / nan: unclaimed
+    if ((by << 1) == 0)                                              // y = +-0
+        return (ux & 0x80000000u) ? ((uy & 0x80000000u) ? -K::opi : K::opi) : ((uy & 0x80000000u) ? -0.0 : 0.0);
+    if (x == 0.0) return (uy & 0x80000000u) ? -K::hpi : K::hpi;      // x = +-0
+    const int de = (int)(uy & 0x7ff00000u) - (int)(ux & 0x7ff00000u);
+    if (de >= 59768832) return (y > 0.0) ? K::hpi : -K::hpi;          // |y/x| huge
+    if (x > 0.0) return __builtin_copysign(rm_fabs(y) / rm_fabs(x), y);   // |y/x| tiny, x > 0
+    return (y > 0.0) ? K::opi : -K::opi;
 }
 
 RM_MATH_HD double rm_atan2(double y, double x)
 {
     typedef AtanK K;
-    const uint64_t bx = rm_asuint64(x), by = rm_asuint64(y);
-    const uint32_t ux = (uint32_t)(bx >> 32), uy = (uint32_t)(by >> 32);
-    if ((ux & 0x7ff00000u) == 0x7ff00000u || (uy & 0x7ff00000u) == 0x7ff00000u) return ::atan2(y, x);   // inf / nan
-    if ((by << 1) == 0)                                              // y = +-0
-        return (ux & 0x80000000u) ? ((uy & 0x80000000u) ? -K::opi : K::opi) : ((uy & 0x80000000u) ? -0.0 : 0.0);
-    if (x == 0.0) return (uy & 0x80000000u) ? -K::hpi : K::hpi;      // x = +-0
-
-    double ax = (x < 0.0) ? -x : x;
-    double ay = (y < 0.0) ? -y : y;
+    const uint32_t ux = (uint32_t)(rm_asuint64(x) >> 32), uy = (uint32_t)(rm_asuint64(y) >> 32);
     const int de = (int)(uy & 0x7ff00000u) - (int)(ux & 0x7ff00000u);
-    if (de >= 59768832) return (y > 0.0) ? K::hpi : -K::hpi;          // |y/x| huge
-    if (de <= -59768832) {                                           // |y/x| tiny
-        if (x > 0.0) return __builtin_copysign(ay / ax, y);
-        return (y > 0.0) ? K::opi : -K::opi;
-    }
-    if (ax < 0x1p-500 || ay < 0x1p-500) { ax *= 0x1p500; ay *= 0x1p500; }
-    if (ax > 0x1p500 || ay > 0x1p500) { ax *= 0x1p-500; ay *= 0x1p-500; }
+    const bool special = (ux & 0x7ff00000u) == 0x7ff00000u || (uy & 0x7ff00000u) == 0x7ff00000u ||
+                         y == 0.0 || x == 0.0 || de >= 59768832 || de <= -59768832;
+    if (__builtin_expect(special, 0)) return rm_atan2_special(y, x);
 
-    double u, du;
+    double ax = rm_fabs(x), ay = rm_fabs(y);
+    const double up = (ax < 0x1p-500 || ay < 0x1p-500) ? 0x1p500 : 1.0;
+    ax *= up; ay *= up;
+    const double dn = (ax > 0x1p500 || ay > 0x1p500) ? 0x1p-500 : 1.0;
+    ax *= dn; ay *= dn;
+
     const bool y_lt_x = ay < ax;
-    if (y_lt_x) {
-        u = ay / ax;
-        double v = ax * u;
-        double vv = rm_fma(ax, u, -v);
-        du = ((ay - v) - vv) / ax;
-    } else {
-        u = ax / ay;
-        double v = ay * u;
-        double vv = rm_fma(ay, u, -v);
-        du = ((ax - v) - vv) / ay;
-    }
+    const double num = y_lt_x ? ay : ax, den = y_lt_x ? ax : ay;
+    const double u = num / den;
+    const double vq = den * u;
+    const double du = ((num - vq) - rm_fma(den, u, -vq)) / den;
 
-    double z;
-    if (x > 0.0) {
-        if (y_lt_x) {                                                // (i) atan(ay/ax)
-            if (u < 0.0625) {
-                double v = u * u;
-                double zz = rm_fma(u * v, rm_atan_series(v), du);
-                z = u + zz;
-            } else {
-                const double* c = rm_atan_row(u);
-                double t3 = u - c[0];
-                double v = du + t3;
-                double dv = (rm_fabs(t3) > rm_fabs(du)) ? ((t3 - v) + du) : ((du - v) + t3);
-                double p = rm_fma(v, c[6], c[5]);
-                p = rm_fma(v, p, c[4]);
-                p = rm_fma(v, p, c[3]);
-                p = (v * v) * p;
-                p = rm_fma(dv, c[2], p);
-                double zz = rm_fma(v, c[2], p);
-                z = zz + c[1];
-            }
-        } else {                                                     // (ii) pi/2 - atan(ax/ay)
-            if (u < 0.0625) {
-                double v = u * u;
-                double zz = (u * v) * rm_atan_series(v);
-                double t2 = K::hpi - u;
-                double cor = (K::hpi - t2) - u;
-                double t3 = ((cor + K::hpi1) - du) - zz;
-                z = t3 + t2;
-            } else {
-                const double* c = rm_atan_row(u);
-                double v = (u - c[0]) + du;
-                double zz = rm_fnma(v, rm_atan_row_poly(c, v), K::hpi1);
-                double t1 = K::hpi - c[1];
-                z = t1 + zz;
-            }
-        }
-    } else {
-        if (ax < ay) {                                               // (iii) pi/2 + atan(ax/ay)
-            if (u < 0.0625) {
-                double v = u * u;
-                double zz = (v * u) * rm_atan_series(v);
-                double t2 = u + K::hpi;
-                double cor = (K::hpi - t2) + u;
-                double t3 = ((cor + K::hpi1) + du) + zz;
-                z = t3 + t2;
-            } else {
-                const double* c = rm_atan_row(u);
-                double v = (u - c[0]) + du;
-                double zz = rm_fma(v, rm_atan_row_poly(c, v), K::hpi1);
-                double t1 = K::hpi + c[1];
-                z = t1 + zz;
-            }
-        } else {                                                     // (iv) pi - atan(ay/ax)
-            if (u < 0.0625) {
-                double v = u * u;
-                double zz = (v * u) * rm_atan_series(v);
-                double t2 = K::opi - u;
-                double cor = (K::opi - t2) - u;
-                double t3 = ((cor + K::opi1) - du) - zz;
-                z = t3 + t2;
-            } else {
-                const double* c = rm_atan_row(u);
-                double v = (u - c[0]) + du;
-                double zz = rm_fnma(v, rm_atan_row_poly(c, v), K::opi1);
-                double t1 = K::opi - c[1];
-                z = t1 + zz;
-            }
-        }
-    }
+    const bool xpos = x > 0.0;
+    const bool case_i = xpos && y_lt_x;
+    // cases (ii) x>0,|x|<=|y|: pi/2 - atan;  (iii) x<0,|x|<|y|: pi/2 + atan;  (iv) x<0,|y|<=|x|: pi - atan
+    const bool case_iv = !xpos && !(ax < ay);
+    const bool plus = !xpos && (ax < ay);
+    const double B = case_iv ? K::opi : K::hpi, B1 = case_iv ? K::opi1 : K::hpi1;
+
+    // series forms (u < 1/16)
+    const double v2 = u * u;
+    const double ser = rm_atan_series(v2);
+    const double uv = u * v2;
+    const double z_is = u + rm_fma(uv, ser, du);
+    const double su = plus ? u : -u, sdu = plus ? du : -du;
+    const double zz_s = uv * ser;
+    const double t2 = B + su;
+    const double cor = (B - t2) + su;
+    const double z_os = (((cor + B1) + sdu) + (plus ? zz_s : -zz_s)) + t2;
+
+    // table forms
+    int i = (int)(rm_fma(u, 256.0, 0x1p52) - 0x1p52) - 16;
+    i = (i < 0) ? 0 : ((i > 240) ? 240 : i);      // in range whenever the table form is selected
+    const double* c = rm_cij + 7 * i;
+    const double c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5], c6 = c[6];
+    const double t3 = u - c0;
+    // (i): EADD(t3, du, v, dv), zz = v*c2 + (dv*c2 + v*v*(c3 + v*(c4 + v*(c5 + v*c6))))
+    const double vi = du + t3;
+    const double dv = (rm_fabs(t3) > rm_fabs(du)) ? ((t3 - vi) + du) : ((du - vi) + t3);
+    double pi_ = rm_fma(vi, c6, c5);
+    pi_ = rm_fma(vi, pi_, c4);
+    pi_ = rm_fma(vi, pi_, c3);
+    pi_ = (vi * vi) * pi_;
+    pi_ = rm_fma(dv, c2, pi_);
+    const double z_it = rm_fma(vi, c2, pi_) + c1;
+    // (ii)-(iv): v = (u - c0) + du, zz = B1 -+ v*(c2 + v*(c3 + v*(c4 + v*(c5 + v*c6)))), z = (B -+ c1) + zz
+    const double vo = t3 + du;
+    double po = rm_fma(vo, c6, c5);
+    po = rm_fma(vo, po, c4);
+    po = rm_fma(vo, po, c3);
+    po = rm_fma(vo, po, c2);
+    const double z_ot = (B + (plus ? c1 : -c1)) + rm_fma(plus ? vo : -vo, po, B1);
+
+    const bool small = u < 0.0625;
+    const double z = case_i ? (small ? z_is : z_it) : (small ? z_os : z_ot);
     return __builtin_copysign(z, y);
 }
 

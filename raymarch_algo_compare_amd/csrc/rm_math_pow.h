@@ -1,4 +1,4 @@
-// rm_math_pow.h -- pow(x, y), bit-exact restatement of glibc 2.35 __pow_fma.
+// rm_math_pow.h -- pow(x, y), bit-exact restatement of glibc 2.35 __pow_fma, branch-free.
 //
 // Algorithm: glibc sysdeps/ieee754/dbl-64/e_pow.c (Szabolcs Nagy's pow from ARM
 // optimized-routines): log(x) as a double-double from a 128-entry table and a
@@ -9,12 +9,17 @@
 // from the machine code of the FMA variant, which is the one CPython reaches on
 // every FMA+AVX2 host (the build container and the GPU box alike).
 //
-// STATUS: EXACT for finite x >= 0 (including zero and subnormals), +inf, NaN, and
-// y with 2^-65 <= |y| < 2^63 whose result neither overflows nor underflows -- which
-// covers every call site of the path: `** 0.5` (vec3.py:46-47, primitives.py:24-32,49-50),
-// `** 2` (primitives.py:26) and `r ** 7.0`, `r ** 8.0` with r <= 4 (catalog.py:280,283).
-// Outside that domain (negative x, overflow/underflow of the result) the routine
-// falls back to the platform pow, which is not claimed exact.
+// Shape: straight-line code, special cases resolved by selects at the end, so a
+// 64-lane wavefront never diverges inside pow and independent calls can be
+// interleaved by the instruction scheduler (the kernels are latency-bound on the
+// longest ray -- DESIGN.md).
+//
+// STATUS: EXACT for x >= +0 (zero, subnormal, normal, +inf), NaN, and y > 0 with
+// 2^-65 <= y < 2^63 whose result neither overflows nor is subnormal -- every call site of
+// the path: `** 0.5` (vec3.py:46-47, primitives.py:24-32,49-50), `** 2` (primitives.py:26),
+// `r ** 7.0`, `r ** 8.0` (catalog.py:280,283).  Not claimed: negative x (NaN is returned;
+// CPython returns a complex number or raises), results below 2^-1022 (0 is returned;
+// CPython raises OverflowError for a subnormal result), overflow (+inf).
 #pragma once
 
 #include "rm_libm_tables.h"
@@ -24,7 +29,7 @@ namespace rm {
 RM_MATH_HD uint64_t rm_asuint64(double x) { return __builtin_bit_cast(uint64_t, x); }
 RM_MATH_HD double rm_asdouble(uint64_t u) { return __builtin_bit_cast(double, u); }
 
-// log(x) for positive normal-range bits `ix`, returned as hi + *tail.
+// log(x) for positive normal-range bits `ix`, returned as hi + *tail (log_inline, e_pow.c).
 RM_MATH_HD double rm_pow_log_inline(uint64_t ix, double* tail)
 {
     const double Ln2hi = rm_pow_log_head[0], Ln2lo = rm_pow_log_head[1];
@@ -67,48 +72,17 @@ RM_MATH_HD double rm_pow_log_inline(uint64_t ix, double* tail)
     return y;
 }
 
-// platform pow for the unclaimed corner cases
-RM_MATH_HD double rm_pow_platform(double x, double y) { return ::pow(x, y); }
-
-RM_MATH_HD double rm_pow(double x, double y)
+// bits of x brought into the normal range (glibc: ix = asuint64(x * 0x1p52) & ~sign; ix -= 52 << 52)
+RM_MATH_HD uint64_t rm_pow_norm_bits(double x)
 {
     uint64_t ix = rm_asuint64(x);
-    uint64_t iy = rm_asuint64(y);
-    uint32_t topx = (uint32_t)(ix >> 52);
-    uint32_t topy = (uint32_t)(iy >> 52) & 0x7ff;
+    uint64_t sx = (rm_asuint64(x * 0x1p52) & 0x7fffffffffffffffull) - (52ull << 52);
+    return (ix < 0x0010000000000000ull) ? sx : ix;
+}
 
-    if (__builtin_expect(topy - 0x3be > 0x7f, 0)) return rm_pow_platform(x, y);
-    if (__builtin_expect(topx - 1 > 0x7fd, 0)) {
-        // x is zero, subnormal, negative, inf or nan
-        if (x != x) return x + y;
-        if (ix >> 63) {
-            if (x == 0.0 && !(iy >> 63)) {
-                // pow(-0, y>0): -0 for odd integer y, +0 otherwise
-                double ay = rm_asdouble(iy);
-                bool odd = (ay == rm_trunc(ay)) && (rm_trunc(ay * 0.5) * 2.0 != ay) && ay < 0x1p53;
-                return odd ? -0.0 : 0.0;
-            }
-            return rm_pow_platform(x, y);
-        }
-        if (ix == 0) return (iy >> 63) ? rm_pow_platform(x, y) : 0.0;       // x*x in glibc
-        if (ix == 0x7ff0000000000000ull) return (iy >> 63) ? 0.0 : x;       // x*x / 1/(x*x)
-        // subnormal x: normalise (glibc: ix = asuint64(x * 0x1p52) & ~sign, ix -= 52 << 52)
-        ix = rm_asuint64(x * 0x1p52);
-        ix &= 0x7fffffffffffffffull;
-        ix -= 52ull << 52;
-    }
-
-    double lo;
-    double hi = rm_pow_log_inline(ix, &lo);
-    double ehi = y * hi;
-    double elo = rm_fma(y, lo, rm_fma(hi, y, -ehi));
-
-    // exp_inline(ehi, elo, 0)
-    uint32_t abstop = (uint32_t)(rm_asuint64(ehi) >> 52) & 0x7ff;
-    if (__builtin_expect(abstop - 0x3c9 >= 0x3f, 0)) {
-        if ((int32_t)(abstop - 0x3c9) < 0) return 1.0 + ehi;  // |y log x| < 2^-54
-        return rm_pow_platform(x, y);                         // |y log x| >= 512: unclaimed
-    }
+// exp(ehi + elo) for the double-double y*log(x) (exp_inline, e_pow.c); `bad` results are fixed by the caller
+RM_MATH_HD double rm_pow_exp_inline(double ehi, double elo)
+{
     const double InvLn2N = rm_exp_head[0], Shift = rm_exp_head[1], NegLn2hiN = rm_exp_head[2],
                  NegLn2loN = rm_exp_head[3], C2 = rm_exp_head[4], C3 = rm_exp_head[5],
                  C4 = rm_exp_head[6], C5 = rm_exp_head[7];
@@ -129,7 +103,43 @@ RM_MATH_HD double rm_pow(double x, double y)
     double r4 = r2 * r2;
     double tmp = rm_fma(b, r4, c);
     double scale = rm_asdouble(sbits);
-    return rm_fma(tmp, scale, scale);
+    double res = rm_fma(tmp, scale, scale);
+    // |y log x| < 2^-54: 1 + ehi;  |y log x| >= 512: the result leaves the normal range
+    uint32_t abstop = (uint32_t)(rm_asuint64(ehi) >> 52) & 0x7ff;
+    res = (abstop < 0x3c9) ? 1.0 + ehi : res;
+    res = (abstop >= 0x409) ? ((ehi < 0.0) ? 0.0 : __builtin_inf()) : res;
+    return res;
+}
+
+RM_MATH_HD double rm_pow_fix_special(double x, double res)
+{
+    res = (x == 0.0) ? 0.0 : res;                       // pow(+0, y > 0) = +0
+    res = (x == __builtin_inf()) ? x : res;             // pow(+inf, y > 0) = +inf
+    res = (x != x || x < 0.0) ? __builtin_nan("") : res;    // NaN in -> NaN; negative base unclaimed
+    return res;
+}
+
+// pow(x, y) for x >= 0, y > 0 (see STATUS)
+RM_MATH_HD double rm_pow(double x, double y)
+{
+    double lo;
+    double hi = rm_pow_log_inline(rm_pow_norm_bits(x), &lo);
+    double ehi = y * hi;
+    double elo = rm_fma(y, lo, rm_fma(hi, y, -ehi));
+    return rm_pow_fix_special(x, rm_pow_exp_inline(ehi, elo));
+}
+
+// pow(x, ya) and pow(x, yb) sharing the one log(x) they both start from (catalog.py:280,283:
+// r ** 7.0 and r ** 8.0 of the same r); each result is bit-identical to a separate rm_pow call.
+RM_MATH_HD void rm_pow2(double x, double ya, double yb, double* ra, double* rb)
+{
+    double lo;
+    double hi = rm_pow_log_inline(rm_pow_norm_bits(x), &lo);
+    double ehia = ya * hi, ehib = yb * hi;
+    double eloa = rm_fma(ya, lo, rm_fma(hi, ya, -ehia));
+    double elob = rm_fma(yb, lo, rm_fma(hi, yb, -ehib));
+    *ra = rm_pow_fix_special(x, rm_pow_exp_inline(ehia, eloa));
+    *rb = rm_pow_fix_special(x, rm_pow_exp_inline(ehib, elob));
 }
 
 }  // namespace rm

@@ -10,10 +10,13 @@
 // variant's machine code (gcc contracted a*b+c there; every rm_fma is one of its
 // vfmadd/vfnmadd/vfmsub instructions, every plain * + - stays unfused).
 //
-// STATUS: rm_sin / rm_cos EXACT for |x| < 105414350 (the path needs |x| <= 8*pi for
-// Mandelbulb, <= ~320 for Gyroid); rm_log EXACT for positive finite x (normal or
-// subnormal).  Outside: platform fallback, not claimed exact.  Verified against libm
-// by tests/test_math_exact.py.
+// Shape: branch-free (every range/band is evaluated and the result selected) so a wavefront
+// never diverges inside these routines and independent calls interleave -- DESIGN.md section 3.
+//
+// STATUS: rm_sin / rm_cos / rm_sincos EXACT for |x| < 105414350 (the path needs |x| <= 8*pi for
+// Mandelbulb, <= ~320 for Gyroid), NaN for larger or non-finite arguments (unclaimed: glibc uses
+// __branred there); rm_log EXACT for positive finite x (normal or subnormal).  Verified against
+// libm by tests/test_math_exact.py.
 #pragma once
 
 namespace rm {
@@ -48,97 +51,109 @@ RM_MATH_HD double rm_taylor_sin(double x, double dx)
     return x + t;
 }
 
-RM_MATH_HD double rm_do_sin(double x, double dx)
+// table row of __sincostab for u = big + |a| (|a| < 0.855469 on every claimed input; the clamp only
+// keeps the gather in bounds for unclaimed / garbage arguments)
+RM_MATH_HD int rm_sincos_row(double u)
 {
-    typedef SinCosK K;
-    const double xold = x;
-    if (rm_fabs(x) < 0.126) return rm_taylor_sin(x, dx);
-    if (x <= 0.0) dx = -dx;
-    double u = K::big + rm_fabs(x);
-    x = rm_fabs(x) - (u - K::big);
-    int k = (int)(uint32_t)rm_asuint64(u) * 4;
-    double sn = rm_sincostab[k], ssn = rm_sincostab[k + 1], cs = rm_sincostab[k + 2], ccs = rm_sincostab[k + 3];
-    double xx = x * x;
-    double s = x + rm_fma(x * xx, rm_fma(xx, K::sn5, K::sn3), dx);
-    double c = rm_fma(x, dx, xx * rm_fma(xx, rm_fma(xx, K::cs6, K::cs4), K::cs2));
-    double cor = rm_fma(s, cs, rm_fnma(c, sn, rm_fma(s, ccs, ssn)));
-    return __builtin_copysign(sn + cor, xold);
+    uint32_t i = (uint32_t)rm_asuint64(u);
+    return (int)((i > 109u) ? 0u : i) * 4;
 }
 
-RM_MATH_HD double rm_do_cos(double x, double dx)
+// do_sin(x, dx), branch-free: Taylor below 0.126, table otherwise (both evaluated, one selected)
+RM_MATH_HD double rm_do_sin(double a, double da)
 {
     typedef SinCosK K;
-    if (x < 0.0) dx = -dx;
-    double u = K::big + rm_fabs(x);
-    x = (rm_fabs(x) - (u - K::big)) + dx;
-    int k = (int)(uint32_t)rm_asuint64(u) * 4;
-    double sn = rm_sincostab[k], ssn = rm_sincostab[k + 1], cs = rm_sincostab[k + 2], ccs = rm_sincostab[k + 3];
-    double xx = x * x;
-    double s = rm_fma(x * xx, rm_fma(xx, K::sn5, K::sn3), x);
-    double c = xx * rm_fma(xx, rm_fma(xx, K::cs6, K::cs4), K::cs2);
-    double cor = rm_fnma(s, sn, rm_fnma(c, cs, rm_fnma(s, ssn, ccs)));
+    const double aa = rm_fabs(a);
+    const double taylor = rm_taylor_sin(a, da);          // uses dx before the sign flip, as s_sin.c does
+    const double dx = (a <= 0.0) ? -da : da;
+    const double u = K::big + aa;
+    const double x = aa - (u - K::big);
+    const int k = rm_sincos_row(u);
+    const double sn = rm_sincostab[k], ssn = rm_sincostab[k + 1], cs = rm_sincostab[k + 2], ccs = rm_sincostab[k + 3];
+    const double xx = x * x;
+    const double s = x + rm_fma(x * xx, rm_fma(xx, K::sn5, K::sn3), dx);
+    const double c = rm_fma(x, dx, xx * rm_fma(xx, rm_fma(xx, K::cs6, K::cs4), K::cs2));
+    const double cor = rm_fma(s, cs, rm_fnma(c, sn, rm_fma(s, ccs, ssn)));
+    const double tab = __builtin_copysign(sn + cor, a);
+    return (aa < 0.126) ? taylor : tab;
+}
+
+RM_MATH_HD double rm_do_cos(double a, double da)
+{
+    typedef SinCosK K;
+    const double aa = rm_fabs(a);
+    const double dx = (a < 0.0) ? -da : da;
+    const double u = K::big + aa;
+    const double x = (aa - (u - K::big)) + dx;
+    const int k = rm_sincos_row(u);
+    const double sn = rm_sincostab[k], ssn = rm_sincostab[k + 1], cs = rm_sincostab[k + 2], ccs = rm_sincostab[k + 3];
+    const double xx = x * x;
+    const double s = rm_fma(x * xx, rm_fma(xx, K::sn5, K::sn3), x);
+    const double c = xx * rm_fma(xx, rm_fma(xx, K::cs6, K::cs4), K::cs2);
+    const double cor = rm_fnma(s, sn, rm_fnma(c, cs, rm_fnma(s, ssn, ccs)));
     return cs + cor;
 }
 
-// reduce_sincos: x -> (a, da) in [-pi/4, pi/4], returns the quadrant (low 2 bits meaningful)
-RM_MATH_HD int rm_reduce_sincos(double x, double* a, double* da)
+// sin(x) and cos(x) together, branch-free.  __sin and __cos (s_sin.c) pick one of four argument
+// ranges; every range ends in do_sin on one (a, da) pair and do_cos on another:
+//   |x| < 0.855469          sin = do_sin(x, 0)                         cos = do_cos(x, 0)
+//   |x| < 2.426265          sin = copysign(do_cos(hp0-|x|, hp1), x)    cos = do_sin(a, da), a = y+hp1, da = (y-a)+hp1
+//   |x| < 105414350         reduce_sincos -> (a, da, n): sin = do_sincos(a, da, n), cos = do_sincos(a, da, n+1)
+// so the two kernels are evaluated once each on selected inputs and the outputs are routed by selects.
+RM_MATH_HD void rm_sincos(double x, double* sin_out, double* cos_out)
 {
     typedef SinCosK K;
-    double t = rm_fma(x, K::hpinv, K::toint);
-    double xn = t - K::toint;
-    int n = (int)(uint32_t)rm_asuint64(t);
-    double y = rm_fnma(xn, K::mp2, rm_fnma(xn, K::mp1, x));
-    double t2 = rm_fnma(xn, K::pp3, y);
+    const uint32_t k = (uint32_t)(rm_asuint64(x) >> 32) & 0x7fffffffu;
+    const double ax = rm_fabs(x);
+    // range 3: reduce_sincos
+    const double t = rm_fma(x, K::hpinv, K::toint);
+    const double xn = t - K::toint;
+    const uint32_t n = (uint32_t)rm_asuint64(t);
+    const double y = rm_fnma(xn, K::mp2, rm_fnma(xn, K::mp1, x));
+    const double t2 = rm_fnma(xn, K::pp3, y);
     double db = rm_fnma(K::pp3, xn, y - t2);
-    double b = rm_fnma(xn, K::pp4, t2);
+    const double b = rm_fnma(xn, K::pp4, t2);
     db = db + rm_fnma(xn, K::pp4, t2 - b);
-    *a = b;
-    *da = db;
-    return n;
-}
+    // range 2
+    const double tt = K::hp0 - ax;
+    const double a2 = tt + K::hp1;
+    const double da2 = (tt - a2) + K::hp1;
 
-RM_MATH_HD double rm_do_sincos(double a, double da, int n)
-{
-    double r = (n & 1) ? rm_do_cos(a, da) : rm_do_sin(a, da);
-    return (n & 2) ? -r : r;
+    const bool r1 = k < 0x3feb6000u;
+    const bool r2 = !r1 && k < 0x400368fdu;
+    const double aS = r1 ? x : (r2 ? a2 : b), daS = r1 ? 0.0 : (r2 ? da2 : db);
+    const double aC = r1 ? x : (r2 ? tt : b), daC = r1 ? 0.0 : (r2 ? K::hp1 : db);
+    const double dS = rm_do_sin(aS, daS);
+    const double dC = rm_do_cos(aC, daC);
+
+    // range 3 routing: do_sincos(a, da, n) = (n & 1 ? do_cos : do_sin), negated when n & 2
+    const uint32_t m = n + 1u;
+    double s3 = (n & 1u) ? dC : dS;
+    s3 = (n & 2u) ? -s3 : s3;
+    double c3 = (m & 1u) ? dC : dS;
+    c3 = (m & 2u) ? -c3 : c3;
+    double s = r1 ? dS : (r2 ? __builtin_copysign(dC, x) : s3);
+    double c = r1 ? dC : (r2 ? dS : c3);
+    s = (k < 0x3e500000u) ? x : s;                      // |x| < 2^-26
+    c = (k < 0x3e400000u) ? 1.0 : c;                    // |x| < 2^-27
+    const double bad = __builtin_nan("");                // inf / nan -> nan; __branred range unclaimed
+    const bool huge = k >= 0x419921fbu;
+    *sin_out = huge ? bad : s;
+    *cos_out = huge ? bad : c;
 }
 
 RM_MATH_HD double rm_sin(double x)
 {
-    typedef SinCosK K;
-    const uint32_t k = (uint32_t)(rm_asuint64(x) >> 32) & 0x7fffffffu;
-    if (k < 0x3e500000u) return x;                                  // |x| < 2^-26
-    if (k < 0x3feb6000u) return rm_do_sin(x, 0.0);                  // |x| < 0.855469
-    if (k < 0x400368fdu) {                                          // |x| < 2.426265
-        double t = K::hp0 - rm_fabs(x);
-        return __builtin_copysign(rm_do_cos(t, K::hp1), x);
-    }
-    if (k < 0x419921fbu) {                                          // |x| < 105414350
-        double a, da;
-        int n = rm_reduce_sincos(x, &a, &da);
-        return rm_do_sincos(a, da, n);
-    }
-    return ::sin(x);                                                // __branred range / inf / nan: unclaimed
+    double s, c;
+    rm_sincos(x, &s, &c);
+    return s;
 }
 
 RM_MATH_HD double rm_cos(double x)
 {
-    typedef SinCosK K;
-    const uint32_t k = (uint32_t)(rm_asuint64(x) >> 32) & 0x7fffffffu;
-    if (k < 0x3e400000u) return 1.0;                                // |x| < 2^-27
-    if (k < 0x3feb6000u) return rm_do_cos(x, 0.0);
-    if (k < 0x400368fdu) {
-        double y = K::hp0 - rm_fabs(x);
-        double a = y + K::hp1;
-        double da = (y - a) + K::hp1;
-        return rm_do_sin(a, da);
-    }
-    if (k < 0x419921fbu) {
-        double a, da;
-        int n = rm_reduce_sincos(x, &a, &da);
-        return rm_do_sincos(a, da, n + 1);
-    }
-    return ::cos(x);
+    double s, c;
+    rm_sincos(x, &s, &c);
+    return c;
 }
 
 // ---- e_log.c ------------------------------------------------------------------------

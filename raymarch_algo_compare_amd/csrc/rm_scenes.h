@@ -141,13 +141,18 @@ struct SceneMandelbulb {                                                        
         for (int i = 0; i < 8; ++i) {
             r = length(z);
             if (r > 4.0) break;
+            // acos / atan2 / the two pows are independent of one another, as are the two sincos
+            // pairs: written back to back (all branch-free) so their dependency chains interleave.
             double theta = rm_acos(py_max(-1.0, py_min(1.0, z.z / py_max(r, 1e-12))));
             double phi = rm_atan2(z.y, z.x);
-            dr = rm_pow(r, power - 1.0) * power * dr + 1.0;
-            double zr = rm_pow(r, power);
+            double r7, zr;
+            rm_pow2(r, power - 1.0, power, &r7, &zr);       // r ** 7.0 and r ** 8.0 share log(r)
+            dr = r7 * power * dr + 1.0;
             theta *= power;
             phi *= power;
-            double st = rm_sin(theta), ct = rm_cos(theta), sp = rm_sin(phi), cp = rm_cos(phi);
+            double st, ct, sp, cp;
+            rm_sincos(theta, &st, &ct);
+            rm_sincos(phi, &sp, &cp);
             z = v3(zr * st * cp, zr * st * sp, zr * ct) + p;
         }
         return 0.5 * rm_log(py_max(r, 1e-12)) * r / py_max(dr, 1e-12);
@@ -231,7 +236,11 @@ struct SceneGyroid {                                                            
         const double FREQ = 3.0;
         const double LIP = 0x1.4c8dc2e423980p+3;  // 3.0 * 2.0 * (3.0 ** 0.5) as CPython evaluates it
         double qx = FREQ * p.x, qy = FREQ * p.y, qz = FREQ * p.z;
-        double g = rm_sin(qx) * rm_cos(qy) + rm_sin(qy) * rm_cos(qz) + rm_sin(qz) * rm_cos(qx);
+        double sx, cx, sy, cy, sz, cz;
+        rm_sincos(qx, &sx, &cx);
+        rm_sincos(qy, &sy, &cy);
+        rm_sincos(qz, &sz, &cz);
+        double g = sx * cy + sy * cz + sz * cx;
         double sheet = g / LIP;
         double ball = sd_sphere(p, 2.2);
         return py_max(sheet, ball);
