@@ -148,15 +148,19 @@ int make_args(const RmFrameDesc* d, float* depth, int32_t* iters, uint8_t* hit, 
     a->depth = depth; a->iters = iters; a->hit = hit; a->t_raw = traw; a->final_sdf = fs;
     a->block_var = bvar; a->stats = stats;
     *tile_h = th;
+    // persistent grid of 4-wave workgroups; every wave pulls tiles on its own
     const long long ntiles = (long long)a->tiles_x * a->tiles_y;
-    int waves = d->grid_waves;
-    if (waves <= 0) {
+    const long long max_wgs = (ntiles + rm::kWavesPerWG - 1) / rm::kWavesPerWG;
+    long long wgs;
+    if (d->grid_waves > 0) {
+        wgs = (d->grid_waves + rm::kWavesPerWG - 1) / rm::kWavesPerWG;
+    } else {
         int per_cu = 0;
         hipError_t e = rm::scene(d->scene_id)->occupancy(d->strategy_id, th, &per_cu);
-        if (e != hipSuccess || per_cu <= 0) per_cu = 8;
-        waves = g.prop.multiProcessorCount * per_cu;
+        if (e != hipSuccess || per_cu <= 0) per_cu = 2;
+        wgs = (long long)g.prop.multiProcessorCount * per_cu;
     }
-    *grid = (int)std::max<long long>(1, std::min<long long>(waves, ntiles));
+    *grid = (int)std::max<long long>(1, std::min<long long>(wgs, max_wgs));
     return RM_OK;
 }
 

@@ -6,9 +6,12 @@
 // MetricsCollector.benchmark_strategy (metrics/collector.py:40-44).
 //
 // Execution shape (CDNA4, 64-lane wavefronts; VALU/fp64 bound, not HBM bound):
-//  * one wavefront per workgroup, persistent: each wave pulls 64 x TILE_H pixel
-//    tiles from a global atomic counter until none are left (every wave reaches
-//    the exit test, the grid always drains);
+//  * persistent 256-thread workgroups (4 waves); each WAVE independently pulls
+//    64 x TILE_H pixel tiles from a global atomic counter until none are left (every
+//    wave reaches the exit test, the grid always drains).  The four waves share one
+//    LDS copy of the glibc lookup tables their scene needs (<= 47 KB for Mandelbulb):
+//    the table gathers of the exact libm restatements are dependent loads on the
+//    critical path of every ray, and LDS latency is several times lower than L2's;
 //  * one ray per lane, all per-ray state in VGPRs.  A lane that finishes its ray
 //    takes the next unassigned pixel of the wave's tile ("lane refill"), so a
 //    512-step straggler ray does not idle the other 63 lanes; refills are batched
@@ -21,6 +24,8 @@
 //    kernel exit, and the reference's 8x4-block "warp divergence" variance
 //    numerators (core/types.py:125-133) reduced in-wave with DPP shuffles.
 #pragma once
+
+#define RM_TABLES_IN_LDS 1   // device math reads the LDS mirror filled by rm_load_tables()
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -72,19 +77,64 @@ __device__ __forceinline__ void store_raw(const KernelArgs& a, int x0, int y0, i
     }
 }
 
+constexpr int kWavesPerWG = 4;         // 256-thread workgroups: four waves share one LDS copy of the libm tables
+
+// Copy the gathered libm tables this scene needs from constant memory into LDS (all threads of the
+// workgroup cooperate; ends with a barrier).  With RM_TABLES_IN_LDS the math headers read rm_s_*.
+template <class T>
+__device__ __forceinline__ void copy_table(T* dst, const T* src, int n)
+{
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+
+template <class Scene>
+__device__ __forceinline__ void rm_load_tables()
+{
+#if defined(__HIP_DEVICE_COMPILE__) && defined(RM_TABLES_IN_LDS)
+    constexpr unsigned tb = SceneTables<Scene>::value;
+    if constexpr (tb & TB_POW) {
+        copy_table(rm_s_pow_log_tab, rm_g_pow_log_tab, 512);
+        copy_table(rm_s_exp_tab, rm_g_exp_tab, 256);
+    }
+    if constexpr (tb & TB_SINCOS) copy_table(rm_s_sincostab, rm_g_sincostab, 440);
+    if constexpr (tb & TB_ACOS) {
+        copy_table(rm_s_asncs, rm_g_asncs, 2568);
+        copy_table(rm_s_inroot, rm_g_inroot, 128);
+    }
+    if constexpr (tb & TB_ATAN) copy_table(rm_s_cij, rm_g_cij, 1687);
+    if constexpr (tb & TB_LOG) copy_table(rm_s_log_tab, rm_g_log_tab, 256);
+    __syncthreads();
+#endif
+}
+
+// Orders this wave's earlier LDS accesses before its later ones (cross-lane hand-off through a
+// wave-private LDS region; DS operations of one wave execute in order, this stops the compiler
+// from reordering them and is free at run time).
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <class Scene, class Strat, int TILE_H>
-__global__ __launch_bounds__(64) void render_kernel(const KernelArgs a)
+__global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelArgs a)
 {
     constexpr int TILE_PIX = kTileW * TILE_H;
-    __shared__ float s_depth[TILE_PIX];
-    __shared__ int32_t s_iters[TILE_PIX];
-    __shared__ uint8_t s_hit[TILE_PIX];
+    __shared__ float s_depth_all[kWavesPerWG][TILE_PIX];
+    __shared__ int32_t s_iters_all[kWavesPerWG][TILE_PIX];
+    __shared__ uint8_t s_hit_all[kWavesPerWG][TILE_PIX];
     __shared__ unsigned int s_hist[kHistBins];
 
     const int lane = lane_id();
+    const int wave = (int)(threadIdx.x >> 6);
+    float* const s_depth = s_depth_all[wave];
+    int32_t* const s_iters = s_iters_all[wave];
+    uint8_t* const s_hit = s_hit_all[wave];
     const int ntiles = a.tiles_x * a.tiles_y;
 
-    for (int b = lane; b < kHistBins; b += 64) s_hist[b] = 0u;
+    for (int b = threadIdx.x; b < kHistBins; b += blockDim.x) s_hist[b] = 0u;
+    rm_load_tables<Scene>();
+    __syncthreads();
 
     unsigned long long acc_hits = 0, acc_iters = 0, acc_rays = 0;
     int acc_max = 0, acc_min = 0x7fffffff;
@@ -96,7 +146,7 @@ __global__ __launch_bounds__(64) void render_kernel(const KernelArgs a)
         int tile = 0;
         if (lane == 0) tile = (int)atomicAdd(&a.stats[0], 1ull);
         tile = __builtin_amdgcn_readfirstlane(tile);
-        if (tile >= ntiles) break;   // uniform exit, reached by every wave
+        if (tile >= ntiles) break;   // wave-uniform exit, reached by every wave
 
         const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
         const int x0 = tx * kTileW;
@@ -157,7 +207,7 @@ __global__ __launch_bounds__(64) void render_kernel(const KernelArgs a)
                 }
             }
         }
-        __syncthreads();   // single-wave workgroup: orders the staged LDS results before the flush
+        wave_lds_fence();   // staged results of all 64 lanes are visible to the flush below
 
         // ---- flush: lane == column; one 64-pixel row per store instruction ----------
         const int gx = x0 + lane;
@@ -196,7 +246,7 @@ __global__ __launch_bounds__(64) void render_kernel(const KernelArgs a)
                 bs = 0; bq = 0;
             }
         }
-        __syncthreads();
+        wave_lds_fence();   // the staging tile may be overwritten by the next tile's rays
     }
 
     // ---- per-wave totals -> one atomic each; histogram flush -----------------------
@@ -214,8 +264,8 @@ __global__ __launch_bounds__(64) void render_kernel(const KernelArgs a)
         atomicMax(&a.stats[4], (unsigned long long)(0x7fffffff - acc_min));   // zero-initialised => store the complement
         atomicAdd(&a.stats[5], acc_rays);
     }
-    __syncthreads();
-    for (int b = lane; b < kHistBins; b += 64) {
+    __syncthreads();   // every wave of the workgroup has left its tile loop
+    for (int b = threadIdx.x; b < kHistBins; b += blockDim.x) {
         const unsigned int c = s_hist[b];
         if (c) atomicAdd(&a.stats[8 + b], (unsigned long long)c);
     }
@@ -226,6 +276,7 @@ __global__ __launch_bounds__(64) void render_kernel(const KernelArgs a)
 template <class Scene>
 __global__ void sdf_eval_kernel(const double* __restrict__ xyz, size_t n, double* __restrict__ out)
 {
+    rm_load_tables<Scene>();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = Scene::sdf(v3(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]));
 }
@@ -234,6 +285,7 @@ template <class Scene, class Strat>
 __global__ void march_rays_kernel(MarchCfg cfg, const double* __restrict__ origins, const double* __restrict__ dirs,
                                   size_t n, uint8_t* hit, double* t, int32_t* iters, double* final_sdf)
 {
+    rm_load_tables<Scene>();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     vec3 o = v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);

@@ -18,14 +18,14 @@ using SceneT = SceneById<RM_SCENE_ID>::type;
 template <class Strat, int TH>
 static hipError_t launch_render(const KernelArgs& a, int grid, hipStream_t s)
 {
-    hipLaunchKernelGGL((render_kernel<SceneT, Strat, TH>), dim3(grid), dim3(64), 0, s, a);
+    hipLaunchKernelGGL((render_kernel<SceneT, Strat, TH>), dim3(grid), dim3(64 * kWavesPerWG), 0, s, a);
     return hipGetLastError();
 }
 
 template <class Strat, int TH>
 static hipError_t occ_render(int* blocks)
 {
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, render_kernel<SceneT, Strat, TH>, 64, 0);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, render_kernel<SceneT, Strat, TH>, 64 * kWavesPerWG, 0);
 }
 
 static hipError_t render(int strategy, int tile_h, const KernelArgs& a, int grid, hipStream_t s)

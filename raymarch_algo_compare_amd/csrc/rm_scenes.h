@@ -9,6 +9,11 @@
 
 namespace rm {
 
+// Which gathered libm tables a scene's SDF reaches (the kernels mirror exactly those in LDS).
+// Every scene needs the pow tables: camera normalisation and length() are `** 0.5`.
+enum : unsigned { TB_POW = 1u, TB_SINCOS = 2u, TB_ACOS = 4u, TB_ATAN = 8u, TB_LOG = 16u };
+template <class Scene> struct SceneTables { static constexpr unsigned value = TB_POW; };
+
 // ---- scenes/primitives.py -----------------------------------------------------
 
 RM_HD double sd_sphere(vec3 p, double radius) { return length(p) - radius; }            // :11-12
@@ -282,6 +287,9 @@ struct SceneMetaballs {                                                         
         return d;
     }
 };
+
+template <> struct SceneTables<SceneMandelbulb> { static constexpr unsigned value = TB_POW | TB_SINCOS | TB_ACOS | TB_ATAN | TB_LOG; };
+template <> struct SceneTables<SceneGyroid> { static constexpr unsigned value = TB_POW | TB_SINCOS; };
 
 #define RM_NUM_SCENES 20
 

@@ -127,8 +127,29 @@ def main():
                 "// algorithms; see rm_math_*.h for the restated routines.  Do not edit.\n"
                 "#pragma once\n#include <stdint.h>\n\n"
                 "#if defined(__HIPCC__)\n#define RM_TAB static __device__ __constant__ const\n"
-                "#define RM_TAB_HOST static const\n#else\n#define RM_TAB static const\n#endif\n\n")
-        f.write("\n".join(parts))
+                "#else\n#define RM_TAB static const\n#endif\n\n")
+        body = "\n".join(parts)
+        import re as _re
+        names = _re.findall(r"RM_TAB (double|uint64_t) (rm_\w+)\[(\d+)\]", body)
+        body = _re.sub(r"RM_TAB (double|uint64_t) rm_(\w+)\[", r"RM_TAB \1 rm_g_\2[", body)
+        f.write(body)
+        # Gathered (per-lane indexed) tables can be mirrored in LDS by the kernels: with
+        # RM_TABLES_IN_LDS defined, device code reads rm_s_* (filled by rm_load_tables, rm_kernels.h).
+        gathered = [n for n in names if not n[1].endswith("_head")]
+        f.write("\n// ---- table access: global constant memory, or the LDS mirror inside the render kernels ----\n")
+        f.write("#if defined(__HIP_DEVICE_COMPILE__) && defined(RM_TABLES_IN_LDS)\n")
+        for ty, nm, cnt in gathered:
+            f.write(f"__shared__ {ty} rm_s_{nm[3:]}[{cnt}];\n")
+        for ty, nm, cnt in gathered:
+            f.write(f"#define {nm} rm_s_{nm[3:]}\n")
+        f.write("#else\n")
+        for ty, nm, cnt in gathered:
+            f.write(f"#define {nm} rm_g_{nm[3:]}\n")
+        f.write("#endif\n")
+        for ty, nm, cnt in names:
+            if nm.endswith("_head"):
+                f.write(f"#define {nm} rm_g_{nm[3:]}\n")
+        f.write("\n")
     print("wrote", OUT)
 
 
