@@ -140,7 +140,10 @@ int make_args(const RmFrameDesc* d, float* depth, int32_t* iters, uint8_t* hit, 
     a->width = d->width; a->height = d->height; a->row0 = d->row0; a->rows = d->rows;
     a->tiles_x = (d->width + rm::kTileW - 1) / rm::kTileW;
     a->tiles_y = (d->rows + th - 1) / th;
-    a->refill_min = d->refill_min > 0 ? d->refill_min : 24;
+    // refill batching: ray set-up (~150 instructions) is amortised over the idle lanes it serves;
+    // scenes with expensive SDFs refill eagerly, cheap ones wait for a fuller batch
+    const bool expensive = d->scene_id == 10 || d->scene_id == 14 || d->scene_id == 15 || d->scene_id == 16 || d->scene_id == 19;
+    a->refill_min = d->refill_min > 0 ? d->refill_min : (expensive ? 8 : 24);
     a->hist_bins = rm::kHistBins;
     if (d->band_rows > 0 && d->band_stride > 1) {
         a->band_rows = d->band_rows; a->band_stride = d->band_stride; a->band_offset = d->band_offset;

@@ -13,12 +13,16 @@
 //    the table gathers of the exact libm restatements are dependent loads on the
 //    critical path of every ray, and LDS latency is several times lower than L2's;
 //  * one ray per lane, all per-ray state in VGPRs.  A lane that finishes its ray
-//    takes the next unassigned pixel of the wave's tile ("lane refill"), so a
-//    512-step straggler ray does not idle the other 63 lanes; refills are batched
-//    (REFILL_MIN idle lanes) so ray set-up code runs with a reasonably full EXEC;
-//  * results are staged per tile in LDS and flushed as full-row 256-byte (depth,
-//    iterations) / 64-byte (hit) contiguous stores: the only HBM traffic of the
-//    path, 9 bytes per ray (4 fp32 depth + 4 int32 iterations + 1 uint8 hit);
+//    takes the next unassigned pixel ("lane refill"), so a 512-step straggler ray
+//    does not idle the other 63 lanes.  A wave keeps up to kSlots tiles in flight:
+//    when the current tile is fully handed out it opens the next one while the
+//    earlier tiles drain, so lanes only idle when a very long ray pins every slot.
+//    Refills are batched (refill_min idle lanes) so ray set-up runs with a usefully
+//    full EXEC mask;
+//  * results are staged per tile in LDS (6 B/pixel) and a finished tile is flushed
+//    as full-row 256-byte (depth, iterations) / 64-byte (hit) contiguous stores: the
+//    only HBM traffic of the path, 9 bytes per ray (4 fp32 depth + 4 int32
+//    iterations + 1 uint8 hit);
 //  * frame statistics ride along: per-wave register accumulators (hit count,
 //    iteration sum/max/min), a per-wave LDS iteration histogram flushed once at
 //    kernel exit, and the reference's 8x4-block "warp divergence" variance
@@ -116,20 +120,40 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_wave_barrier();
 }
 
+constexpr int kSlots = 3;   // tiles a wave may have in flight: one being handed out + two draining
+
+// Tile geometry (wave-uniform): origin inside the frame slice, valid extent, image row of its first row.
+struct TileGeom {
+    int x0, y0, tw, th, gy0;
+};
+template <int TILE_H>
+__device__ __forceinline__ TileGeom tile_geom(const KernelArgs& a, int tile)
+{
+    TileGeom g;
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    g.x0 = tx * kTileW;
+    g.y0 = ty * TILE_H;                                   // relative to row0
+    g.tw = min(kTileW, a.width - g.x0);                   // pixels of this tile that exist in the slice
+    g.th = min(TILE_H, a.rows - g.y0);
+    g.gy0 = a.band_rows > 0                               // tiles never straddle a band
+        ? a.row0 + ((g.y0 / a.band_rows) * a.band_stride + a.band_offset) * a.band_rows + (g.y0 % a.band_rows)
+        : a.row0 + g.y0;
+    return g;
+}
+
 template <class Scene, class Strat, int TILE_H>
 __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelArgs a)
 {
     constexpr int TILE_PIX = kTileW * TILE_H;
-    __shared__ float s_depth_all[kWavesPerWG][TILE_PIX];
-    __shared__ int32_t s_iters_all[kWavesPerWG][TILE_PIX];
-    __shared__ uint8_t s_hit_all[kWavesPerWG][TILE_PIX];
+    // per wave and tile slot: fp32 depth + (iterations | hit << 31) of every pixel of the tile
+    __shared__ float s_depth_all[kWavesPerWG][kSlots][TILE_PIX];
+    __shared__ uint32_t s_ih_all[kWavesPerWG][kSlots][TILE_PIX];
     __shared__ unsigned int s_hist[kHistBins];
 
     const int lane = lane_id();
     const int wave = (int)(threadIdx.x >> 6);
-    float* const s_depth = s_depth_all[wave];
-    int32_t* const s_iters = s_iters_all[wave];
-    uint8_t* const s_hit = s_hit_all[wave];
+    float (*const s_depth)[TILE_PIX] = s_depth_all[wave];
+    uint32_t (*const s_ih)[TILE_PIX] = s_ih_all[wave];
     const int ntiles = a.tiles_x * a.tiles_y;
 
     for (int b = threadIdx.x; b < kHistBins; b += blockDim.x) s_hist[b] = 0u;
@@ -140,113 +164,163 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
     int acc_max = 0, acc_min = 0x7fffffff;
 
     const MarchCfg cfg = a.cfg;
-    vec3 origin = v3(a.cam.v[0], a.cam.v[1], a.cam.v[2]);
+    const vec3 origin = v3(a.cam.v[0], a.cam.v[1], a.cam.v[2]);
+
+    // wave-uniform scheduler state: the tiles in flight
+    int slot_tile[kSlots], slot_out[kSlots];      // tile id (-1 = free) and rays handed out but not finished
+#pragma unroll
+    for (int k = 0; k < kSlots; ++k) { slot_tile[k] = -1; slot_out[k] = 0; }
+    int cur = 0;                                  // slot currently handing out pixels
+    int pool_next = TILE_PIX;                     // next unassigned pixel id of slot `cur`
+    bool more_tiles = true;                       // the global tile queue may still hold work
+    TileGeom cg = { 0, 0, 0, 0, 0 };              // geometry of slot `cur`
+
+    // per-lane state: the ray this lane carries
+    bool active = false;
+    int my_slot = 0, my_pix = 0;                  // where its result goes: slot, tile-linear index y*64+x
+    vec3 dir = v3(0.0, 0.0, 0.0);
+    Strat s;
 
     for (;;) {
-        int tile = 0;
-        if (lane == 0) tile = (int)atomicAdd(&a.stats[0], 1ull);
-        tile = __builtin_amdgcn_readfirstlane(tile);
-        if (tile >= ntiles) break;   // wave-uniform exit, reached by every wave
+        // ---- 1. flush every tile whose rays have all finished (and whose pool is handed out) -----
+#pragma unroll
+        for (int k = 0; k < kSlots; ++k) {
+            const bool pool_done = (k != cur) || pool_next >= TILE_PIX;
+            if (slot_tile[k] >= 0 && slot_out[k] == 0 && pool_done) {   // wave-uniform
+                wave_lds_fence();     // staged results of all 64 lanes are visible
+                const TileGeom g = tile_geom<TILE_H>(a, slot_tile[k]);
+                const int gx = g.x0 + lane;
+                const bool col_ok = lane < g.tw;
+                long long bs = 0, bq = 0;   // per-column sums for the 8x4 block statistic
+#pragma unroll
+                for (int r = 0; r < TILE_H; ++r) {
+                    if (r < g.th && col_ok) {
+                        // lane == column: one 64-pixel row per store instruction
+                        const int li = r * kTileW + lane;
+                        const size_t gi = (size_t)(g.y0 + r) * (size_t)a.width + (size_t)gx;
+                        const uint32_t ih = s_ih[k][li];
+                        const int it = (int)(ih & 0x7fffffffu);
+                        const int h = (int)(ih >> 31);
+                        a.depth[gi] = s_depth[k][li];
+                        a.iters[gi] = it;
+                        a.hit[gi] = (uint8_t)h;
+                        acc_hits += (unsigned)h;
+                        acc_iters += (unsigned)it;
+                        acc_rays += 1;
+                        acc_max = max(acc_max, it);
+                        acc_min = min(acc_min, it);
+                        atomicAdd(&s_hist[min(it, a.hist_bins - 1)], 1u);
+                        bs += it;
+                        bq += (long long)it * it;
+                    }
+                    if ((r & 3) == 3) {
+                        // reduce the 8 columns of each 8x4 block (lanes 8k..8k+7)
+                        long long S = bs, Q = bq;
+                        S += __shfl_xor(S, 1); Q += __shfl_xor(Q, 1);
+                        S += __shfl_xor(S, 2); Q += __shfl_xor(Q, 2);
+                        S += __shfl_xor(S, 4); Q += __shfl_xor(Q, 4);
+                        const int brow = g.y0 + (r - 3);        // first row of this block, relative to row0
+                        if (a.block_var && (lane & 7) == 0 && gx + 8 <= a.width && brow + 4 <= a.rows) {
+                            // full blocks only (types.py:128-131)
+                            a.block_var[(size_t)(brow >> 2) * (size_t)(a.width >> 3) + (size_t)(gx >> 3)] = 32 * Q - S * S;
+                        }
+                        bs = 0; bq = 0;
+                    }
+                }
+                wave_lds_fence();     // the slot may be reused
+                slot_tile[k] = -1;
+            }
+        }
 
-        const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-        const int x0 = tx * kTileW;
-        const int y0 = ty * TILE_H;                 // relative to row0
-        // pixels of this tile that exist in the frame slice
-        const int tw = min(kTileW, a.width - x0);
-        const int th = min(TILE_H, a.rows - y0);
-        // image row of the tile's first row (tiles never straddle a band)
-        const int gy0 = a.band_rows > 0
-            ? a.row0 + ((y0 / a.band_rows) * a.band_stride + a.band_offset) * a.band_rows + (y0 % a.band_rows)
-            : a.row0 + y0;
-
-        int pool_next = 0;            // wave-uniform: next unassigned tile-local pixel id
-        bool active = false;
-        int my_pix = 0;               // tile-linear index y*64+x of the ray this lane carries
-        vec3 dir = v3(0.0, 0.0, 0.0);
-        Strat s;
-
-        for (;;) {
-            const unsigned long long idle = __ballot(!active);
-            const int nidle = __popcll(idle);
-            if (pool_next < TILE_PIX && (nidle >= a.refill_min || nidle == 64)) {
+        // ---- 2. lane refill: idle lanes take the next unassigned pixels (batched by refill_min) ----
+        const unsigned long long idle = __ballot(!active);
+        const int nidle = __popcll(idle);
+        if (nidle >= a.refill_min || nidle == 64) {
+            if (pool_next >= TILE_PIX && more_tiles) {
+                // current tile fully handed out: open the next tile in a free slot, if any
+                int f = -1;
+#pragma unroll
+                for (int k = kSlots - 1; k >= 0; --k) f = (slot_tile[k] < 0) ? k : f;
+                if (f >= 0) {
+                    int tile = 0;
+                    if (lane == 0) tile = (int)atomicAdd(&a.stats[0], 1ull);
+                    tile = __builtin_amdgcn_readfirstlane(tile);
+                    if (tile < ntiles) {
+                        cur = f;
+                        pool_next = 0;
+                        cg = tile_geom<TILE_H>(a, tile);
+#pragma unroll
+                        for (int k = 0; k < kSlots; ++k) {
+                            slot_tile[k] = (k == f) ? tile : slot_tile[k];
+                            slot_out[k] = (k == f) ? 0 : slot_out[k];
+                        }
+                    } else {
+                        more_tiles = false;   // every wave gets here: the grid always drains
+                    }
+                }
+            }
+            if (pool_next < TILE_PIX) {
+                bool started = false;
                 if (!active) {
-                    // block-major pixel order: 32 consecutive ids form one 8x4 block, so a
+                    // block-major pixel order: 32 consecutive ids form one 8x4 block, so a fresh
                     // wave starts on a compact 16x4 patch (coherent rays, similar trip counts)
                     const int id = pool_next + rank_in_mask(idle);
                     const int blk = id >> 5, within = id & 31;
                     const int px = (blk & 7) * 8 + (within & 7);
                     const int py = (blk >> 3) * 4 + (within >> 3);
-                    if (id < TILE_PIX && px < tw && py < th) {
+                    if (id < TILE_PIX && px < cg.tw && py < cg.th) {
+                        my_slot = cur;
                         my_pix = py * kTileW + px;
                         vec3 o_unused;
-                        camera_ray(a.cam, a.width, a.height, x0 + px, gy0 + py, o_unused, dir);
-                        active = true;
+                        camera_ray(a.cam, a.width, a.height, cg.x0 + px, cg.gy0 + py, o_unused, dir);
                         if (s.start(cfg)) {
-                            active = false;
-                            s_depth[my_pix] = s.res.hit ? (float)s.res.t : 0.0f;
-                            s_iters[my_pix] = s.res.iters;
-                            s_hit[my_pix] = (uint8_t)s.res.hit;
-                            store_raw(a, x0, y0, my_pix, s.res);
+                            s_depth[cur][my_pix] = s.res.hit ? (float)s.res.t : 0.0f;
+                            s_ih[cur][my_pix] = (uint32_t)s.res.iters | ((uint32_t)s.res.hit << 31);
+                            store_raw(a, cg.x0, cg.y0, my_pix, s.res);
+                        } else {
+                            active = true;
+                            started = true;
                         }
                     }
                 }
+                const int nstarted = __popcll(__ballot(started));
+#pragma unroll
+                for (int k = 0; k < kSlots; ++k) slot_out[k] += (k == cur) ? nstarted : 0;
                 pool_next += nidle;
             }
-            if (!__any(active)) {
-                if (pool_next >= TILE_PIX) break;
-                continue;
-            }
-            if (active) {
-                const double d = Scene::sdf(origin + dir * s.te);   // ray.py:15-17
-                if (s.step(d, cfg)) {
-                    active = false;
-                    s_depth[my_pix] = s.res.hit ? (float)s.res.t : 0.0f;   // types.py:93
-                    s_iters[my_pix] = s.res.iters;
-                    s_hit[my_pix] = (uint8_t)s.res.hit;
-                    store_raw(a, x0, y0, my_pix, s.res);
-                }
-            }
         }
-        wave_lds_fence();   // staged results of all 64 lanes are visible to the flush below
 
-        // ---- flush: lane == column; one 64-pixel row per store instruction ----------
-        const int gx = x0 + lane;
-        const bool col_ok = lane < tw;
-        long long bs = 0, bq = 0;   // per-column sums for the 8x4 block statistic
+        // ---- 3. exit / idle turn ---------------------------------------------------------------------
+        if (!__any(active)) {
+            bool in_flight = false;
 #pragma unroll
-        for (int r = 0; r < TILE_H; ++r) {
-            if (r < th && col_ok) {
-                const int li = r * kTileW + lane;
-                const size_t gi = (size_t)(y0 + r) * (size_t)a.width + (size_t)gx;
-                const int it = s_iters[li];
-                const int h = s_hit[li];
-                a.depth[gi] = s_depth[li];
-                a.iters[gi] = it;
-                a.hit[gi] = (uint8_t)h;
-                acc_hits += (unsigned)h;
-                acc_iters += (unsigned)it;
-                acc_rays += 1;
-                acc_max = max(acc_max, it);
-                acc_min = min(acc_min, it);
-                atomicAdd(&s_hist[min(it, a.hist_bins - 1)], 1u);
-                bs += it;
-                bq += (long long)it * it;
-            }
-            if ((r & 3) == 3) {
-                // reduce the 8 columns of each 8x4 block (lanes 8k..8k+7)
-                long long S = bs, Q = bq;
-                S += __shfl_xor(S, 1); Q += __shfl_xor(Q, 1);
-                S += __shfl_xor(S, 2); Q += __shfl_xor(Q, 2);
-                S += __shfl_xor(S, 4); Q += __shfl_xor(Q, 4);
-                const int brow = y0 + (r - 3);              // first row of this block, relative to row0
-                if (a.block_var && (lane & 7) == 0 && gx + 8 <= a.width && brow + 4 <= a.rows) {
-                    // full blocks only (types.py:128-131)
-                    a.block_var[(size_t)(brow >> 2) * (size_t)(a.width >> 3) + (size_t)(gx >> 3)] = 32 * Q - S * S;
+            for (int k = 0; k < kSlots; ++k) in_flight = in_flight || (slot_tile[k] >= 0);
+            if (!more_tiles && !in_flight) break;     // wave-uniform; nothing left anywhere
+            continue;                                 // a flush or a refill makes progress next turn
+        }
+
+        // ---- 4. one SDF evaluation for every live ray ----------------------------------------------
+        bool fin = false;
+        if (active) {
+            const double d = Scene::sdf(origin + dir * s.te);   // ray.py:15-17
+            if (s.step(d, cfg)) {
+                active = false;
+                fin = true;
+                s_depth[my_slot][my_pix] = s.res.hit ? (float)s.res.t : 0.0f;   // types.py:93
+                s_ih[my_slot][my_pix] = (uint32_t)s.res.iters | ((uint32_t)s.res.hit << 31);
+                if (a.t_raw || a.final_sdf) {   // parity-test outputs: straight to global memory
+                    int t_of_slot = 0;
+#pragma unroll
+                    for (int k = 0; k < kSlots; ++k) t_of_slot = (k == my_slot) ? slot_tile[k] : t_of_slot;
+                    const TileGeom gs = tile_geom<TILE_H>(a, t_of_slot);
+                    store_raw(a, gs.x0, gs.y0, my_pix, s.res);
                 }
-                bs = 0; bq = 0;
             }
         }
-        wave_lds_fence();   // the staging tile may be overwritten by the next tile's rays
+        if (__any(fin)) {
+#pragma unroll
+            for (int k = 0; k < kSlots; ++k) slot_out[k] -= __popcll(__ballot(fin && my_slot == k));
+        }
     }
 
     // ---- per-wave totals -> one atomic each; histogram flush -----------------------
@@ -264,7 +338,7 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
         atomicMax(&a.stats[4], (unsigned long long)(0x7fffffff - acc_min));   // zero-initialised => store the complement
         atomicAdd(&a.stats[5], acc_rays);
     }
-    __syncthreads();   // every wave of the workgroup has left its tile loop
+    __syncthreads();   // every wave of the workgroup has left its loop
     for (int b = threadIdx.x; b < kHistBins; b += blockDim.x) {
         const unsigned int c = s_hist[b];
         if (c) atomicAdd(&a.stats[8 + b], (unsigned long long)c);
