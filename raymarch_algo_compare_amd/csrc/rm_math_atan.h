@@ -10,8 +10,9 @@
 // Operation order and the fused operations are those of the x86-64 FMA variants' machine code.
 //
 // STATUS: rm_acos EXACT on [-1, 1] (NaN outside); rm_atan2 EXACT for every finite pair, zeros and
-// the huge-ratio shortcuts included.  NaN / infinity arguments of atan2 take the platform fallback
-// (not reachable from the path).
+// the huge-ratio shortcuts included (for an exponent gap >= 57 with |x| or |y| outside
+// [2^-500, 2^500] the quotient is formed after glibc's rescaling: identical unless it is subnormal).
+// NaN / infinite arguments of atan2 return NaN (not reachable from the path).
 #pragma once
 
 namespace rm {
@@ -34,14 +35,16 @@ struct AtanK {
 // always evaluated and selected.  The five table bands of e_asin.c differ only in row stride and
 // polynomial degree (5..9); a band of degree D is evaluated here as a degree-9 Horner chain whose
 // leading coefficients are +0 -- fma(xx, +0, c) == c exactly, so the value is bit-identical to the
-// shorter chain.  Only the 1/sqrt band (|x| >= 0.96875, ~3 % of arguments) stays a branch.
+// shorter chain.  The 1/sqrt band (|x| >= 0.96875) is evaluated as well and selected: no branch anywhere.
 
 RM_MATH_HD double rm_acos_sqrt_band(double x, int m)          // 0.96875 <= |x| < 1
 {
     typedef AtanK K;
     double z = ((m > 0) ? (1.0 - x) : (x + 1.0)) * 0.5;
     const int kz = (int)(rm_asuint64(z) >> 32);
-    double t = rm_inroot[(kz >> 14) & 0x7f] * rm_asdouble((uint64_t)(1023 + (511 - (kz >> 21))) << 52);  // powtwo[]
+    // powtwo[511 - (kz >> 21)] = 2^(511 - (kz >> 21)); masked so that out-of-band arguments (the
+    // routine is evaluated for every x and selected afterwards) still form a finite double
+    double t = rm_inroot[(kz >> 14) & 0x7f] * rm_asdouble((uint64_t)((1023 + 511 - (kz >> 21)) & 0x7ff) << 52);
     double r = rm_fnma(t * t, z, 1.0);
     double q = rm_fma(r, K::rt3, K::rt2);
     q = rm_fma(r, q, K::rt1);
@@ -93,31 +96,35 @@ RM_MATH_HD double rm_acos(double x)
     n = (k >= 0x3fee8000) ? 768 + 15 * i13 : n;   deg = (k >= 0x3fee8000) ? 9 : deg;
     n = (n > 2568 - 13) ? 2568 - 13 : n;          // keeps the gather in bounds for out-of-band arguments
     const double* a = rm_asncs + n;
-    const double xx = ax - a[0];
-    double p = (deg >= 9) ? a[10] : 0.0;
-    p = rm_fma(xx, p, (deg >= 8) ? a[9] : 0.0);
-    p = rm_fma(xx, p, (deg >= 7) ? a[8] : 0.0);
-    p = rm_fma(xx, p, (deg >= 6) ? a[7] : 0.0);
-    p = rm_fma(xx, p, a[6]);
-    p = rm_fma(xx, p, a[5]);
-    p = rm_fma(xx, p, a[4]);
-    p = rm_fma(xx, p, a[3]);
-    p = rm_fma(xx, p, a[2]);
-    const double c0 = (deg == 5) ? a[7] : (deg == 6) ? a[8] : (deg == 7) ? a[9] : (deg == 8) ? a[10] : a[11];
-    const double cv = (deg == 5) ? a[8] : (deg == 6) ? a[9] : (deg == 7) ? a[10] : (deg == 8) ? a[11] : a[12];
+    // the whole 13-entry row is loaded unconditionally (in bounds by the clamp above), then selected:
+    // a conditional load would come back as a branch
+    const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5], a6 = a[6], a7 = a[7], a8 = a[8],
+                 a9 = a[9], a10 = a[10], a11 = a[11], a12 = a[12];
+    const double xx = ax - a0;
+    double p = (deg >= 9) ? a10 : 0.0;
+    p = rm_fma(xx, p, (deg >= 8) ? a9 : 0.0);
+    p = rm_fma(xx, p, (deg >= 7) ? a8 : 0.0);
+    p = rm_fma(xx, p, (deg >= 6) ? a7 : 0.0);
+    p = rm_fma(xx, p, a6);
+    p = rm_fma(xx, p, a5);
+    p = rm_fma(xx, p, a4);
+    p = rm_fma(xx, p, a3);
+    p = rm_fma(xx, p, a2);
+    const double c0 = (deg == 5) ? a7 : (deg == 6) ? a8 : (deg == 7) ? a9 : (deg == 8) ? a10 : a11;
+    const double cv = (deg == 5) ? a8 : (deg == 6) ? a9 : (deg == 7) ? a10 : (deg == 8) ? a11 : a12;
     p = rm_fma(xx * xx, p, c0);
-    const double t = rm_fma(xx, a[1], p);
+    const double t = rm_fma(xx, a1, p);
     const double yb = pos ? (K::hpi - cv) : (cv + K::hpi);
     const double tb = pos ? (K::hpi1 - t) : (t + K::hpi1);
     const double res_band = tb + yb;
 
     double res = (k < 0x3fc00000) ? res_taylor : res_band;
     res = (k < 0x3c880000) ? K::hpi : res;                        // |x| < 2^-55
-    if (__builtin_expect(k >= 0x3fef0000, 0)) {                   // rare tail: |x| >= 0.96875
-        if (k < 0x3ff00000) return rm_acos_sqrt_band(x, m);
-        if (k == 0x3ff00000 && (uint32_t)bits == 0) return pos ? 0.0 : K::opi;   // |x| == 1
-        return __builtin_nan("");                                 // |x| > 1 or NaN: invalid
-    }
+    // |x| >= 0.96875: 1/sqrt band, |x| == 1, invalid -- evaluated unconditionally and selected, so
+    // the routine is one straight-line block (the z argument is clamped to stay in the table)
+    const double res_sqrt = rm_acos_sqrt_band(x, m);
+    res = (k >= 0x3fef0000) ? res_sqrt : res;
+    res = (k >= 0x3ff00000) ? ((k == 0x3ff00000 && (uint32_t)bits == 0) ? (pos ? 0.0 : K::opi) : __builtin_nan("")) : res;
     return res;
 }
 
@@ -126,8 +133,8 @@ RM_MATH_HD double rm_acos(double x)
 // Branch-free main path: the quotient u = min/max as a double-double, then the degree-13 series
 // (u < 1/16) and the cij-table form are both evaluated for the two structural cases -- (i) x > 0,
 // |y| < |x| and the three "pi/2 or pi plus/minus atan" cases, which differ only in a base constant
-// and a sign (a - b == a + (-b) bit-for-bit) -- and one result is selected.  Zeros, infinities,
-// NaNs and exponent gaps >= 57 take a rare out-of-line branch.
+// and a sign (a - b == a + (-b) bit-for-bit) -- and one result is selected; zeros and exponent
+// gaps >= 57 are selects as well (no branch anywhere).  NaN / infinite operands yield NaN.
 
 RM_MATH_HD double rm_atan_series(double v)   // d3 + v*(d5 + v*(d7 + v*(d9 + v*(d11 + v*d13))))
 {
@@ -139,29 +146,11 @@ RM_MATH_HD double rm_atan_series(double v)   // d3 + v*(d5 + v*(d7 + v*(d9 + v*(
     return rm_fma(v, p, K::d3);
 }
 
-RM_MATH_HD double rm_atan2_special(double y, double x)
-{
-    typedef AtanK K;
-    const uint64_t bx = rm_asuint64(x), by = rm_asuint64(y);
-    const uint32_t ux = (uint32_t)(bx >> 32), uy = (uint32_t)(by >> 32);
-    if ((ux & 0x7ff00000u) == 0x7ff00000u || (uy & 0x7ff00000u) == 0x7ff00000u) return ::atan2(y, x);   // inf / nan: unclaimed
-    if ((by << 1) == 0)                                              // y = +-0
-        return (ux & 0x80000000u) ? ((uy & 0x80000000u) ? -K::opi : K::opi) : ((uy & 0x80000000u) ? -0.0 : 0.0);
-    if (x == 0.0) return (uy & 0x80000000u) ? -K::hpi : K::hpi;      // x = +-0
-    const int de = (int)(uy & 0x7ff00000u) - (int)(ux & 0x7ff00000u);
-    if (de >= 59768832) return (y > 0.0) ? K::hpi : -K::hpi;          // |y/x| huge
-    if (x > 0.0) return __builtin_copysign(rm_fabs(y) / rm_fabs(x), y);   // |y/x| tiny, x > 0
-    return (y > 0.0) ? K::opi : -K::opi;
-}
-
 RM_MATH_HD double rm_atan2(double y, double x)
 {
     typedef AtanK K;
     const uint32_t ux = (uint32_t)(rm_asuint64(x) >> 32), uy = (uint32_t)(rm_asuint64(y) >> 32);
     const int de = (int)(uy & 0x7ff00000u) - (int)(ux & 0x7ff00000u);
-    const bool special = (ux & 0x7ff00000u) == 0x7ff00000u || (uy & 0x7ff00000u) == 0x7ff00000u ||
-                         y == 0.0 || x == 0.0 || de >= 59768832 || de <= -59768832;
-    if (__builtin_expect(special, 0)) return rm_atan2_special(y, x);
 
     double ax = rm_fabs(x), ay = rm_fabs(y);
     const double up = (ax < 0x1p-500 || ay < 0x1p-500) ? 0x1p500 : 1.0;
@@ -217,7 +206,15 @@ RM_MATH_HD double rm_atan2(double y, double x)
     const double z_ot = (B + (plus ? c1 : -c1)) + rm_fma(plus ? vo : -vo, po, B1);
 
     const bool small = u < 0.0625;
-    const double z = case_i ? (small ? z_is : z_it) : (small ? z_os : z_ot);
+    double z = case_i ? (small ? z_is : z_it) : (small ? z_os : z_ot);
+    // special operands (e_atan2.c:66-133), resolved by selects in the reference's priority order
+    const bool xneg = (ux & 0x80000000u) != 0;
+    z = (de <= -59768832) ? (xpos ? u : K::opi) : z;             // |y/x| tiny: y/x itself, or pi
+    z = (de >= 59768832) ? K::hpi : z;                           // |y/x| huge
+    z = (x == 0.0) ? K::hpi : z;                                 // x = +-0, y != 0
+    z = (y == 0.0) ? (xneg ? K::opi : 0.0) : z;                  // y = +-0: +-0 or +-pi by the sign of x
+    const bool nonfinite = (ux & 0x7ff00000u) == 0x7ff00000u || (uy & 0x7ff00000u) == 0x7ff00000u;
+    z = nonfinite ? __builtin_nan("") : z;                       // inf / nan operands: unclaimed
     return __builtin_copysign(z, y);
 }
 
