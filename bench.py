@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--refill-min", type=int, default=0)
     ap.add_argument("--grid-waves", type=int, default=0)
+    ap.add_argument("--temporal-grid-waves", type=int, default=512,
+                    help="persistent wavefronts for the temporal_order figure (fewer waves = stragglers run alone)")
     args = ap.parse_args()
 
     import torch
@@ -161,6 +163,36 @@ def main():
 
     st = _native.RmStats()
     _native.check(L.rm_read_stats(ctypes.c_void_p(d_stats.data_ptr()), sptr, ctypes.byref(st)))
+
+    # Secondary figure (never `value`): the same frames scheduled longest-tile-first from the per-tile
+    # cost the previous frame left behind (tile_order_mode 1) on a smaller persistent grid.  Every ray
+    # is recomputed; only the order in which tiles are handed to the waves changes.
+    temporal = None
+    if not wl["sharded"]:
+        desc_t = _native.make_desc(scene.id, strat_id, cam, W, H, lipschitz=lip, tile_rows=args.tile_rows,
+                                   refill_min=args.refill_min, grid_waves=args.temporal_grid_waves, tile_order_mode=1)
+
+        def step_t():
+            _native.check(L.rm_render_device(ctypes.byref(desc_t), ctypes.c_void_p(d_depth.data_ptr()),
+                                             ctypes.c_void_p(d_iters.data_ptr()), ctypes.c_void_p(d_hit.data_ptr()),
+                                             ctypes.c_void_p(d_stats.data_ptr()), sptr))
+        for _ in range(max(2, args.warmup)):
+            step_t()
+        barrier()
+        tt0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_t()
+        barrier()
+        temporal = time.perf_counter() - tt0
+
+    # Isolated store path (the flush code of the render kernel, no marching): what "fraction of the HBM
+    # roofline on the write path" can mean for a kernel that writes 9 B per ~20 000 fp64 operations.
+    tm = _native.RmTiming()
+    tm.warmup, tm.repeats = 3, 20
+    store_gbps = None
+    if L.rm_bench_store_path(W, rows_local, ctypes.c_void_p(d_depth.data_ptr()), ctypes.c_void_p(d_iters.data_ptr()),
+                             ctypes.c_void_p(d_hit.data_ptr()), ctypes.byref(tm)) == 0 and tm.ms_median > 0:
+        store_gbps = BYTES_PER_RAY * rows_local * W / (tm.ms_median * 1e-3) / 1e9
     kernel_ms = [a.elapsed_time(b) for a, b in evs]
     local = torch.tensor([elapsed, float(st.total_rays), float(st.sum_iters), sum(kernel_ms) / len(kernel_ms)],
                          dtype=torch.float64, device=dev)
@@ -202,8 +234,17 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel_ms_avg": kms, "bytes_per_ray": BYTES_PER_RAY,
-                         "note": "write-only path, 9 B/ray; the kernel is fp64-VALU / ray-latency bound (DESIGN.md)"},
+                         "store_path_GBps": store_gbps,
+                         "store_path_frac": (store_gbps / HBM_PEAK_GBPS) if store_gbps else None,
+                         "note": "write-only path, 9 B/ray; the kernel is fp64-VALU / ray-latency bound (DESIGN.md); "
+                                 "store_path_* = the kernel's flush code alone at this frame size"},
         }
+        if temporal is not None:
+            line["temporal_order"] = {
+                "value": rays_step * args.steps / temporal / 1e6 if world == 1 else None, "unit": "Mrays/s",
+                "ms_per_step": temporal / args.steps * 1e3, "grid_waves": args.temporal_grid_waves,
+                "note": "tile_order_mode=1: tiles handed out longest-first using the previous frame's per-tile "
+                        "max-iteration map; identical outputs, every ray recomputed; rank-0 local figure"}
         if not args.no_cpu_baseline and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline(scene.id, strat_id, cam, W, H, lip)

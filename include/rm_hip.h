@@ -67,6 +67,13 @@ typedef struct RmFrameDesc {
     int32_t band_rows;
     int32_t band_stride;
     int32_t band_offset;
+    /* Tile scheduling order.  0: natural (row-major tiles).  1: longest-first using the per-tile cost
+     * (max iterations) the previous render of the SAME frame shape left in the library workspace --
+     * rays that ran long last frame start first, so they no longer finish last (results are
+     * identical in either mode; only the schedule changes).  Falls back to 0 when no matching
+     * previous frame exists. */
+    int32_t tile_order_mode;
+    int32_t reserved;
 } RmFrameDesc;
 
 /* Frame reduce computed in-kernel (the integer part of RayMarchStats.compute, core/types.py:77-137). */

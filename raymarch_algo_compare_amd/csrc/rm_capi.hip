@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -78,7 +79,10 @@ struct State {
     int device = -1;
     hipStream_t stream = nullptr;
     hipDeviceProp_t prop;
-    Buf stats, depth, iters, hit, traw, fs, bvar, in0, in1, out0, out1, out2, out3;
+    Buf stats, depth, iters, hit, traw, fs, bvar, in0, in1, out0, out1, out2, out3, tcost, torder;
+    // shape of the frame whose per-tile costs sit in `tcost` (tile_order_mode 1 needs a match)
+    long long cost_key[10] = { -1 };
+    bool cost_valid = false;
     hipEvent_t ev[2 * RM_MAX_TIMED];
     bool events = false;
 } g;
@@ -104,6 +108,7 @@ int check_desc(const RmFrameDesc* d)
         return fail(RM_E_BAD_DIMS, "bad frame slice: %dx%d rows [%d,%d)", d->width, d->height, d->row0, d->row0 + d->rows);
     if ((long long)d->width * d->height > (1ll << 31) - 1) return fail(RM_E_BAD_DIMS, "frame too large");
     if (d->tile_rows != 0 && d->tile_rows != 4 && d->tile_rows != 8) return fail(RM_E_BAD_ARG, "tile_rows must be 0, 4 or 8");
+    if (d->tile_order_mode != 0 && d->tile_order_mode != 1) return fail(RM_E_BAD_ARG, "tile_order_mode must be 0 or 1");
     if (d->band_rows < 0 || d->band_stride < 0 || d->band_offset < 0) return fail(RM_E_BAD_ARG, "negative band parameter");
     if (d->band_rows > 0 && d->band_stride > 1) {
         const int th = d->tile_rows ? d->tile_rows : 4;
@@ -145,6 +150,7 @@ int make_args(const RmFrameDesc* d, float* depth, int32_t* iters, uint8_t* hit, 
     const bool expensive = d->scene_id == 10 || d->scene_id == 14 || d->scene_id == 15 || d->scene_id == 16 || d->scene_id == 19;
     a->refill_min = d->refill_min > 0 ? d->refill_min : (expensive ? 8 : 24);
     a->hist_bins = rm::kHistBins;
+    if (const char* e = getenv("RM_DEBUG_DYN_LDS")) a->dyn_lds = atoi(e);   // developer knob: force fewer workgroups per CU
     if (d->band_rows > 0 && d->band_stride > 1) {
         a->band_rows = d->band_rows; a->band_stride = d->band_stride; a->band_offset = d->band_offset;
     }
@@ -167,10 +173,54 @@ int make_args(const RmFrameDesc* d, float* depth, int32_t* iters, uint8_t* hit, 
     return RM_OK;
 }
 
-int launch(const RmFrameDesc* d, const rm::KernelArgs& a, int tile_h, int grid, hipStream_t s)
+// Longest-first tile order from last frame's per-tile cost: a counting sort by descending cost
+// (one workgroup; ties keep no particular order -- the order only affects the schedule).
+__global__ __launch_bounds__(1024) void order_tiles_kernel(const int32_t* __restrict__ cost, int32_t* __restrict__ order, int n)
+{
+    constexpr int BINS = 1024;
+    __shared__ int hist[BINS];
+    for (int b = threadIdx.x; b < BINS; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[min(max(cost[i], 0), BINS - 1)], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int b = BINS - 1; b >= 0; --b) { const int c = hist[b]; hist[b] = run; run += c; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int pos = atomicAdd(&hist[min(max(cost[i], 0), BINS - 1)], 1);
+        order[pos] = i;
+    }
+}
+
+void frame_key(const RmFrameDesc* d, int tile_h, long long* k)
+{
+    k[0] = d->scene_id; k[1] = d->strategy_id; k[2] = d->width; k[3] = d->height; k[4] = d->row0; k[5] = d->rows;
+    k[6] = d->band_rows; k[7] = d->band_stride; k[8] = d->band_offset; k[9] = tile_h;
+}
+
+// One frame: (optional) longest-first tile order from the previous frame's costs, stats reset, render.
+int launch(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, hipStream_t s)
 {
     HIP_TRY(hipMemsetAsync(a.stats, 0, kStatsBytes, s));
     if (d->rows == 0) return RM_OK;
+    const int ntiles = a.tiles_x * a.tiles_y;
+    if (d->tile_order_mode == 1) {
+        int rc;
+        if ((rc = g.tcost.ensure((size_t)ntiles * 4)) || (rc = g.torder.ensure((size_t)ntiles * 4))) return rc;
+        long long key[10];
+        frame_key(d, tile_h, key);
+        if (g.cost_valid && memcmp(key, g.cost_key, sizeof key) == 0) {
+            hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, s, (const int32_t*)g.tcost.p,
+                               (int32_t*)g.torder.p, ntiles);
+            HIP_TRY(hipGetLastError());
+            a.tile_order = (const int32_t*)g.torder.p;
+        }
+        a.tile_cost = (int32_t*)g.tcost.p;      // this frame's costs feed the next frame's order
+        memcpy(g.cost_key, key, sizeof key);
+        g.cost_valid = true;
+    }
     HIP_TRY(rm::scene(d->scene_id)->render(d->strategy_id, tile_h, a, grid, s));
     return RM_OK;
 }
@@ -215,10 +265,9 @@ int timed_launches(const RmFrameDesc* d, const rm::KernelArgs& a, int tile_h, in
     for (int i = 0; i < t->warmup; ++i)
         if ((rc = launch(d, a, tile_h, grid, g.stream))) return rc;
     for (int i = 0; i < t->repeats; ++i) {
-        // the stats/tile-counter reset is part of a frame; the events bracket the kernel only
-        HIP_TRY(hipMemsetAsync(a.stats, 0, kStatsBytes, g.stream));
+        // events bracket one whole frame: stats reset, optional tile ordering, render kernel
         HIP_TRY(hipEventRecord(g.ev[2 * i], g.stream));
-        if (d->rows) HIP_TRY(rm::scene(d->scene_id)->render(d->strategy_id, tile_h, a, grid, g.stream));
+        if ((rc = launch(d, a, tile_h, grid, g.stream))) return rc;
         HIP_TRY(hipEventRecord(g.ev[2 * i + 1], g.stream));
     }
     HIP_TRY(hipStreamSynchronize(g.stream));
@@ -294,7 +343,7 @@ void rm_shutdown(void)
     (void)hipSetDevice(g.device);
     (void)hipStreamSynchronize(g.stream);
     for (Buf* b : { &g.stats, &g.depth, &g.iters, &g.hit, &g.traw, &g.fs, &g.bvar, &g.in0, &g.in1, &g.out0, &g.out1,
-                    &g.out2, &g.out3 })
+                    &g.out2, &g.out3, &g.tcost, &g.torder })
         b->release();
     if (g.events) for (auto& e : g.ev) (void)hipEventDestroy(e);
     g.events = false;

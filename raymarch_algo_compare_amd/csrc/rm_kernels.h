@@ -62,6 +62,9 @@ struct KernelArgs {
     double* final_sdf;        // optional: MarchResult.final_sdf (needs cfg.full)
     long long* block_var;     // optional: (rows/4) x (width/8) variance numerators 32*sum(x^2)-sum(x)^2
     unsigned long long* stats;
+    int32_t dyn_lds;            // extra dynamic LDS bytes per workgroup (occupancy control: 0 = none)
+    const int32_t* tile_order;  // optional: permutation of the tile ids (longest-first schedule)
+    int32_t* tile_cost;         // optional: per tile, the largest iteration count of its rays
 };
 
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -227,6 +230,14 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
                         bs = 0; bq = 0;
                     }
                 }
+                if (a.tile_cost) {
+                    int tmax = 0;
+#pragma unroll
+                    for (int r = 0; r < TILE_H; ++r)
+                        if (r < g.th && col_ok) tmax = max(tmax, (int)(s_ih[k][r * kTileW + lane] & 0x7fffffffu));
+                    for (int off = 32; off > 0; off >>= 1) tmax = max(tmax, __shfl_xor(tmax, off));
+                    if (lane == 0) a.tile_cost[slot_tile[k]] = tmax;
+                }
                 wave_lds_fence();     // the slot may be reused
                 slot_tile[k] = -1;
             }
@@ -246,6 +257,7 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
                     if (lane == 0) tile = (int)atomicAdd(&a.stats[0], 1ull);
                     tile = __builtin_amdgcn_readfirstlane(tile);
                     if (tile < ntiles) {
+                        if (a.tile_order) tile = __builtin_amdgcn_readfirstlane(a.tile_order[tile]);
                         cur = f;
                         pool_next = 0;
                         cg = tile_geom<TILE_H>(a, tile);

@@ -37,3 +37,18 @@ elif exp == "matrix":
     for sid in range(14):
         for key in registry.GRADED_STRATEGY_KEYS:
             run(sid, registry.STRATEGIES[key], repeats=3, warmup=1)
+elif exp == "lpt":
+    for sid, kid in ((10, 0), (10, 4), (12, 0), (13, 0), (0, 0)):
+        run(sid, kid, repeats=7, warmup=2)
+        run(sid, kid, repeats=7, warmup=2, tile_order_mode=1)
+    run(10, 0, W=3840, H=2160, repeats=3, warmup=1)
+    run(10, 0, W=3840, H=2160, repeats=3, warmup=2, tile_order_mode=1)
+elif exp == "lpt2":
+    for gw in (512, 1024, 1536, 2048):
+        run(10, 0, repeats=7, warmup=2, grid_waves=gw)
+        run(10, 0, repeats=7, warmup=2, grid_waves=gw, tile_order_mode=1)
+    for rm_ in (1, 4, 16):
+        run(10, 0, repeats=7, warmup=2, refill_min=rm_, tile_order_mode=1)
+elif exp == "lpt3":
+    for gw in (256, 384, 512, 640, 768, 1024, 2048):
+        run(10, 0, repeats=5, warmup=2, grid_waves=gw, tile_order_mode=1)
