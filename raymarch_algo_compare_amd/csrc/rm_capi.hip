@@ -108,7 +108,7 @@ int check_desc(const RmFrameDesc* d)
         return fail(RM_E_BAD_DIMS, "bad frame slice: %dx%d rows [%d,%d)", d->width, d->height, d->row0, d->row0 + d->rows);
     if ((long long)d->width * d->height > (1ll << 31) - 1) return fail(RM_E_BAD_DIMS, "frame too large");
     if (d->tile_rows != 0 && d->tile_rows != 4 && d->tile_rows != 8) return fail(RM_E_BAD_ARG, "tile_rows must be 0, 4 or 8");
-    if (d->tile_order_mode != 0 && d->tile_order_mode != 1) return fail(RM_E_BAD_ARG, "tile_order_mode must be 0 or 1");
+    if (d->tile_order_mode < 0 || d->tile_order_mode > 2) return fail(RM_E_BAD_ARG, "tile_order_mode must be 0, 1 or 2");
     if (d->band_rows < 0 || d->band_stride < 0 || d->band_offset < 0) return fail(RM_E_BAD_ARG, "negative band parameter");
     if (d->band_rows > 0 && d->band_stride > 1) {
         const int th = d->tile_rows ? d->tile_rows : 4;
@@ -194,6 +194,21 @@ __global__ __launch_bounds__(1024) void order_tiles_kernel(const int32_t* __rest
     }
 }
 
+// Static centre-out priority: tiles nearer the image centre (where the camera looks) get a higher cost.
+__global__ void center_cost_kernel(int32_t* __restrict__ cost, int tiles_x, int tiles_y, int tile_h, int width, int height,
+                                   int row0, int band_rows, int band_stride, int band_offset)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tiles_x * tiles_y) return;
+    const int tx = t % tiles_x, ty = t / tiles_x;
+    const int y0 = ty * tile_h;
+    const int gy = band_rows > 0 ? row0 + ((y0 / band_rows) * band_stride + band_offset) * band_rows + (y0 % band_rows) : row0 + y0;
+    const float cx = (tx * 64 + 32 - 0.5f * width) / (0.5f * height);      // both axes in units of half the image height
+    const float cy = (gy + 0.5f * tile_h - 0.5f * height) / (0.5f * height);
+    const float r = sqrtf(cx * cx + cy * cy);
+    cost[t] = max(0, 1023 - (int)(r * 256.0f));
+}
+
 void frame_key(const RmFrameDesc* d, int tile_h, long long* k)
 {
     k[0] = d->scene_id; k[1] = d->strategy_id; k[2] = d->width; k[3] = d->height; k[4] = d->row0; k[5] = d->rows;
@@ -220,6 +235,15 @@ int launch(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, hipStre
         a.tile_cost = (int32_t*)g.tcost.p;      // this frame's costs feed the next frame's order
         memcpy(g.cost_key, key, sizeof key);
         g.cost_valid = true;
+    } else if (d->tile_order_mode == 2) {
+        int rc;
+        if ((rc = g.tcost.ensure((size_t)ntiles * 4)) || (rc = g.torder.ensure((size_t)ntiles * 4))) return rc;
+        g.cost_valid = false;                   // tcost is overwritten with the static priorities
+        hipLaunchKernelGGL(center_cost_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, s, (int32_t*)g.tcost.p, a.tiles_x,
+                           a.tiles_y, tile_h, a.width, a.height, a.row0, a.band_rows, a.band_stride, a.band_offset);
+        hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, s, (const int32_t*)g.tcost.p, (int32_t*)g.torder.p, ntiles);
+        HIP_TRY(hipGetLastError());
+        a.tile_order = (const int32_t*)g.torder.p;
     }
     HIP_TRY(rm::scene(d->scene_id)->render(d->strategy_id, tile_h, a, grid, s));
     return RM_OK;

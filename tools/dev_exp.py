@@ -52,3 +52,7 @@ elif exp == "lpt2":
 elif exp == "lpt3":
     for gw in (256, 384, 512, 640, 768, 1024, 2048):
         run(10, 0, repeats=5, warmup=2, grid_waves=gw, tile_order_mode=1)
+elif exp == "center":
+    for sid, kid in ((10, 0), (10, 4), (12, 0), (0, 0), (13, 0)):
+        for gw in (512, 768, 1024, 2048):
+            run(sid, kid, repeats=7, warmup=2, grid_waves=gw, tile_order_mode=2)
