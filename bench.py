@@ -44,7 +44,7 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(scene_id, strategy_id, cam14, width, height, lipschitz):
+def cpu_baseline(scene_id, strategy_id, cam14, width, height, lipschitz, gpu_maps=None):
     """Oracle (CPU restatement of the reference, oracle/rm_oracle.c) on a bounded sample of the
     same workload (about 10-30 s of CPU work): every host thread on the whole frame (capped at
     1080 rows) + one thread on 24 centre rows."""
@@ -61,7 +61,19 @@ def cpu_baseline(scene_id, strategy_id, cam14, width, height, lipschitz):
     t1 = time.perf_counter()
     oracle.render(scene_id, strategy_id, cam14, width, height, row0=r1, rows=rows_1t, lipschitz=lipschitz, nthreads=1)
     dt1 = time.perf_counter() - t1
+    parity = None
+    if gpu_maps is not None:
+        # the oracle frame is already here: use it as the checker for the GPU maps of the timed run
+        import numpy as np
+        g_depth, g_iters, g_hit = gpu_maps
+        sl = slice(r0, r0 + rows_mt)
+        both = (g_hit[sl] > 0) & (fr.hit > 0)
+        parity = {"iter_mismatch_count": int((g_iters[sl] != fr.iters).sum()),
+                  "hit_mismatch_count": int((g_hit[sl] != fr.hit).sum()),
+                  "max_abs_depth_err": float(np.abs(g_depth[sl].astype(np.float64) - fr.t)[both].max()) if both.any() else 0.0,
+                  "rays_compared": int(fr.iters.size)}
     return {
+        "parity_vs_oracle": parity,
         "value": rows_mt * width / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
         "sample": f"rows {r0}..{r0 + rows_mt - 1} of the {width}x{height} frame ({rows_mt * width} rays, "
                   f"{dt:.2f} s, OpenMP over rows); mean iters/ray of the sample {float(fr.iters.mean()):.2f}",
@@ -190,8 +202,9 @@ def main():
     tm = _native.RmTiming()
     tm.warmup, tm.repeats = 3, 20
     store_gbps = None
-    if L.rm_bench_store_path(W, rows_local, ctypes.c_void_p(d_depth.data_ptr()), ctypes.c_void_p(d_iters.data_ptr()),
-                             ctypes.c_void_p(d_hit.data_ptr()), ctypes.byref(tm)) == 0 and tm.ms_median > 0:
+    p_depth, p_iters, p_hit = torch.empty_like(d_depth), torch.empty_like(d_iters), torch.empty_like(d_hit)   # probe scratch
+    if L.rm_bench_store_path(W, rows_local, ctypes.c_void_p(p_depth.data_ptr()), ctypes.c_void_p(p_iters.data_ptr()),
+                             ctypes.c_void_p(p_hit.data_ptr()), ctypes.byref(tm)) == 0 and tm.ms_median > 0:
         store_gbps = BYTES_PER_RAY * rows_local * W / (tm.ms_median * 1e-3) / 1e9
     kernel_ms = [a.elapsed_time(b) for a, b in evs]
     local = torch.tensor([elapsed, float(st.total_rays), float(st.sum_iters), sum(kernel_ms) / len(kernel_ms)],
@@ -247,7 +260,8 @@ def main():
                         "max-iteration map; identical outputs, every ray recomputed; rank-0 local figure"}
         if not args.no_cpu_baseline and world == 1:
             try:
-                line["cpu_baseline"] = cpu_baseline(scene.id, strat_id, cam, W, H, lip)
+                maps = (d_depth.cpu().numpy(), d_iters.cpu().numpy(), d_hit.cpu().numpy()) if plan is None else None
+                line["cpu_baseline"] = cpu_baseline(scene.id, strat_id, cam, W, H, lip, maps)
             except Exception as e:  # the oracle is a checker; a failure here must not hide the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port",
                                         "sample": f"unavailable: {e}"}
