@@ -148,6 +148,22 @@ int rm_read_stats(const void* d_stats, void* stream, RmStats* out);
 int rm_bench_device(const RmFrameDesc* desc, void* d_depth, void* d_iters, void* d_hit, RmStats* stats,
                     RmTiming* timing);
 
+/* N frames of one (scene, strategy, frame shape) rendered in ONE launch: the reference's real
+ * workload is sweeps of many small frames -- curated viewpoints (viewpoints.py:41-140) and
+ * iteration-budget / epsilon levels (sweep.py:96-127) -- and a small frame is bound by the latency
+ * of its longest ray, not by throughput.  The tiles of all frames feed one persistent grid (every
+ * ray carries its own frame's camera origin and march configuration), so the long-ray tails of the
+ * frames overlap and the whole device stays busy.
+ *   shape     scene / strategy / width / height / row0 / rows (cam and march of `shape` are ignored)
+ *   cams      nframes x 14 doubles (one camera per frame, as RmFrameDesc.cam)
+ *   configs   nframes march configs, or NULL to use shape->march for every frame
+ *   depth / iters / hit   host arrays of nframes x rows x width elements (frame-major)
+ *   stats     nframes RmStats or NULL;  ms_total  device time of the batch launch (hipEvents) or NULL
+ *   all configs must share `full`; tile_order_mode must be 0
+ * Every frame is bit-identical to what rm_render returns for it alone. */
+int rm_render_batch(const RmFrameDesc* shape, int32_t nframes, const double* cams, const RmMarchConfig* configs,
+                    float* depth, int32_t* iters, uint8_t* hit, RmStats* stats, float* ms_total);
+
 /* Library-owned device frame buffers for callers without their own allocator. */
 int rm_alloc_frame(int32_t width, int32_t rows, void** d_depth, void** d_iters, void** d_hit);
 int rm_free_frame(void* d_depth, void* d_iters, void* d_hit);

@@ -25,7 +25,7 @@ EXPORTS = [
     "rm_init", "rm_shutdown", "rm_last_error", "rm_device_info", "rm_num_scenes", "rm_num_strategies",
     "rm_sdf_eval", "rm_march_rays", "rm_render", "rm_render_device", "rm_stats_device_bytes",
     "rm_read_stats", "rm_bench_device", "rm_alloc_frame", "rm_free_frame", "rm_copy_frame_to_host",
-    "rm_bench_store_path",
+    "rm_bench_store_path", "rm_render_batch",
 ]
 
 
@@ -102,6 +102,8 @@ def load() -> ctypes.CDLL:
         L.rm_read_stats.argtypes = [vp, vp, ctypes.POINTER(RmStats)]
         L.rm_bench_device.argtypes = [ctypes.POINTER(RmFrameDesc), vp, vp, vp, ctypes.POINTER(RmStats),
                                       ctypes.POINTER(RmTiming)]
+        L.rm_render_batch.argtypes = [ctypes.POINTER(RmFrameDesc), ctypes.c_int32, dp, ctypes.POINTER(RmMarchConfig),
+                                      vp, vp, vp, ctypes.POINTER(RmStats), ctypes.POINTER(ctypes.c_float)]
         L.rm_alloc_frame.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(vp), ctypes.POINTER(vp),
                                      ctypes.POINTER(vp)]
         L.rm_free_frame.argtypes = [vp, vp, vp]
@@ -208,6 +210,36 @@ def render(desc: RmFrameDesc, want_t_raw=False, want_final_sdf=False, want_block
                       ctypes.byref(tm) if tm is not None else None))
     out["stats"] = stats_dict(st)
     out["timing"] = timing_dict(tm) if tm is not None else None
+    return out
+
+
+def render_batch(shape: RmFrameDesc, cams, configs=None) -> dict:
+    """rm_render_batch: `cams` is (n, 14); `configs` an optional list of dicts / RmMarchConfig (one per
+    frame).  Returns frame-major depth / iters / hit arrays (n, rows, W), per-frame stats and ms_total."""
+    L = init()
+    cams = np.ascontiguousarray(cams, dtype=np.float64).reshape(-1, 14)
+    n = len(cams)
+    rows, W = shape.rows, shape.width
+    out = {"depth": np.empty((n, rows, W), np.float32), "iters": np.empty((n, rows, W), np.int32),
+           "hit": np.empty((n, rows, W), np.uint8)}
+    cfg_arr = None
+    if configs is not None:
+        if len(configs) != n:
+            raise ValueError("one march config per frame")
+        cfg_arr = (RmMarchConfig * n)()
+        for i, c in enumerate(configs):
+            if isinstance(c, RmMarchConfig):
+                cfg_arr[i] = c
+            else:
+                cfg_arr[i] = RmMarchConfig(int(c.get("max_iterations", 512)), 1 if c.get("full") else 0,
+                                           float(c.get("hit_threshold", 1e-4)), float(c.get("max_distance", 100.0)),
+                                           float(c.get("lipschitz", 1.0)))
+    st = (RmStats * n)()
+    ms = ctypes.c_float(0.0)
+    check(L.rm_render_batch(ctypes.byref(shape), n, cams.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), cfg_arr,
+                            _ptr(out["depth"]), _ptr(out["iters"]), _ptr(out["hit"]), st, ctypes.byref(ms)))
+    out["stats"] = [stats_dict(st[i]) for i in range(n)]
+    out["ms_total"] = float(ms.value)
     return out
 
 

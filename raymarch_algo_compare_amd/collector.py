@@ -42,6 +42,38 @@ class HipCollector:
         return _native.render(desc, want_t_raw=self.full, want_final_sdf=self.full, warmup=warmup,
                               repeats=repeats)
 
+    def benchmark_batch(self, strategy: StrategyInfo, scene: SceneInfo, cameras, configs=None):
+        """Render one frame per camera (optionally one MarchConfig per frame) in ONE launch
+        (rm_render_batch) and return a RayMarchStats per frame -- the shape of the reference's sweeps
+        over curated viewpoints and iteration-budget / epsilon levels (viewpoints.py:41-140,
+        sweep.py:96-127).  Cameras must share the resolution.  fp32 depth (the 9 B/ray path)."""
+        import numpy as np
+        cameras = list(cameras)
+        if not cameras:
+            return []
+        w, h = cameras[0].width, cameras[0].height
+        if any(c.width != w or c.height != h for c in cameras):
+            raise ValueError("all cameras of a batch must share the resolution")
+        _native.init(self.device_id)
+        cfgs = None
+        if configs is not None:
+            cfgs = [dict(max_iterations=c.max_iterations, hit_threshold=c.hit_threshold, max_distance=c.max_distance,
+                         lipschitz=self._lipschitz(strategy)) for c in configs]
+        else:
+            cfgs = [dict(max_iterations=self.config.max_iterations, hit_threshold=self.config.hit_threshold,
+                         max_distance=self.config.max_distance, lipschitz=self._lipschitz(strategy))] * len(cameras)
+        shape = _native.make_desc(scene.id, strategy.id, cameras[0].params14(), w, h, **self.tuning)
+        start = time.perf_counter()
+        out = _native.render_batch(shape, np.stack([c.params14() for c in cameras]), cfgs)
+        elapsed = time.perf_counter() - start
+        res = []
+        for i in range(len(cameras)):
+            st = RayMarchStats(strategy_name=strategy.short_name, scene_name=scene.name)
+            st.compute_from_maps(out["iters"][i], out["hit"][i], out["depth"][i], elapsed / len(cameras))
+            st.kernel_ms = out["ms_total"] / len(cameras)
+            res.append(st)
+        return res
+
     def benchmark_strategy(self, strategy: StrategyInfo, scene: SceneInfo, camera: Camera,
                            verbose: bool = True) -> RayMarchStats:
         width, height = camera.width, camera.height

@@ -85,6 +85,7 @@ struct State {
     bool cost_valid = false;
     hipEvent_t ev[2 * RM_MAX_TIMED];
     bool events = false;
+    Buf bstats;   // rm_render_batch: the device frame table
 } g;
 
 std::mutex g_mu;
@@ -140,11 +141,15 @@ int make_args(const RmFrameDesc* d, float* depth, int32_t* iters, uint8_t* hit, 
 {
     const int th = d->tile_rows ? d->tile_rows : 4;
     memset(a, 0, sizeof *a);
-    for (int i = 0; i < 14; ++i) a->cam.v[i] = d->cam[i];
-    a->cfg = to_cfg(d->march);
+    for (int i = 0; i < 14; ++i) a->single.cam.v[i] = d->cam[i];
+    a->single.cfg = to_cfg(d->march);
+    a->frames = nullptr;
+    a->nframes = 1;
+    a->full = d->march.full ? 1 : 0;
     a->width = d->width; a->height = d->height; a->row0 = d->row0; a->rows = d->rows;
     a->tiles_x = (d->width + rm::kTileW - 1) / rm::kTileW;
     a->tiles_y = (d->rows + th - 1) / th;
+    a->tiles_per_frame = a->tiles_x * a->tiles_y;
     // refill batching: ray set-up (~150 instructions) is amortised over the idle lanes it serves;
     // scenes with expensive SDFs refill eagerly, cheap ones wait for a fuller batch
     const bool expensive = d->scene_id == 10 || d->scene_id == 14 || d->scene_id == 15 || d->scene_id == 16 || d->scene_id == 19;
@@ -220,7 +225,7 @@ int launch(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, hipStre
 {
     HIP_TRY(hipMemsetAsync(a.stats, 0, kStatsBytes, s));
     if (d->rows == 0) return RM_OK;
-    const int ntiles = a.tiles_x * a.tiles_y;
+    const int ntiles = a.tiles_per_frame * a.nframes;
     if (d->tile_order_mode == 1) {
         int rc;
         if ((rc = g.tcost.ensure((size_t)ntiles * 4)) || (rc = g.torder.ensure((size_t)ntiles * 4))) return rc;
@@ -366,11 +371,12 @@ void rm_shutdown(void)
     if (!g.ready) return;
     (void)hipSetDevice(g.device);
     (void)hipStreamSynchronize(g.stream);
-    for (Buf* b : { &g.stats, &g.depth, &g.iters, &g.hit, &g.traw, &g.fs, &g.bvar, &g.in0, &g.in1, &g.out0, &g.out1,
+    for (Buf* b : { &g.bstats, &g.stats, &g.depth, &g.iters, &g.hit, &g.traw, &g.fs, &g.bvar, &g.in0, &g.in1, &g.out0, &g.out1,
                     &g.out2, &g.out3, &g.tcost, &g.torder })
         b->release();
     if (g.events) for (auto& e : g.ev) (void)hipEventDestroy(e);
     g.events = false;
+
     (void)hipStreamDestroy(g.stream);
     g.stream = nullptr;
     g.ready = false;
@@ -530,6 +536,80 @@ int rm_bench_device(const RmFrameDesc* d, void* d_depth, void* d_iters, void* d_
         unsigned long long w[rm::kStatsWords];
         HIP_TRY(hipMemcpy(w, g.stats.p, kStatsBytes, hipMemcpyDeviceToHost));
         decode_stats(w, stats);
+    }
+    return RM_OK;
+}
+
+int rm_render_batch(const RmFrameDesc* shape, int32_t nframes, const double* cams, const RmMarchConfig* configs,
+                    float* depth, int32_t* iters, uint8_t* hit, RmStats* stats, float* ms_total)
+{
+    int rc = check_ready();
+    if (rc) return rc;
+    if ((rc = check_desc(shape))) return rc;
+    if (nframes < 0 || (nframes > 0 && (!cams || !depth || !iters || !hit))) return fail(RM_E_BAD_ARG, "bad batch arguments");
+    if (shape->tile_order_mode != 0) return fail(RM_E_BAD_ARG, "tile_order_mode is not supported for batches");
+    if (nframes == 0) return RM_OK;
+    const int full = configs ? (configs[0].full ? 1 : 0) : (shape->march.full ? 1 : 0);
+    for (int f = 0; configs && f < nframes; ++f)
+        if ((configs[f].full ? 1 : 0) != full) return fail(RM_E_BAD_ARG, "all frames of a batch must share march.full");
+    const size_t n = (size_t)shape->rows * (size_t)shape->width;          // elements per frame
+    const size_t total = n * (size_t)nframes;
+    if (total > (size_t)1 << 31) return fail(RM_E_BAD_DIMS, "batch too large");
+    std::lock_guard<std::mutex> lk(g_mu);
+    HIP_TRY(hipSetDevice(g.device));
+    if ((rc = ensure_events())) return rc;
+    if ((rc = g.depth.ensure(total * 4 + 16)) || (rc = g.iters.ensure(total * 4 + 16)) || (rc = g.hit.ensure(total + 16)) ||
+        (rc = g.bstats.ensure(sizeof(rm::FrameParams) * (size_t)nframes)))
+        return rc;
+    // the frame table: one camera + march configuration per frame
+    std::vector<rm::FrameParams> fp((size_t)nframes);
+    for (int f = 0; f < nframes; ++f) {
+        for (int i = 0; i < 14; ++i) fp[f].cam.v[i] = cams[(size_t)f * 14 + i];
+        fp[f].cfg = to_cfg(configs ? configs[f] : shape->march);
+    }
+    HIP_TRY(hipMemcpyAsync(g.bstats.p, fp.data(), sizeof(rm::FrameParams) * (size_t)nframes, hipMemcpyHostToDevice, g.stream));
+    rm::KernelArgs a;
+    int tile_h = 0, grid = 0;
+    RmFrameDesc d = *shape;
+    if (configs) d.march = configs[0];
+    if ((rc = make_args(&d, (float*)g.depth.p, (int32_t*)g.iters.p, (uint8_t*)g.hit.p, nullptr, nullptr, nullptr,
+                        (unsigned long long*)g.stats.p, &a, &tile_h, &grid)))
+        return rc;
+    a.frames = (const rm::FrameParams*)g.bstats.p;
+    a.nframes = nframes;
+    a.full = full;
+    if (d.grid_waves <= 0) {      // the batch is one big launch: size the persistent grid for all its tiles
+        const long long ntiles = (long long)a.tiles_per_frame * nframes;
+        int per_cu = 0;
+        if (rm::scene(d.scene_id)->occupancy(d.strategy_id, tile_h, &per_cu) != hipSuccess || per_cu <= 0) per_cu = 2;
+        grid = (int)std::max<long long>(1, std::min<long long>((long long)g.prop.multiProcessorCount * per_cu,
+                                                                (ntiles + rm::kWavesPerWG - 1) / rm::kWavesPerWG));
+    }
+    HIP_TRY(hipEventRecord(g.ev[0], g.stream));
+    if ((rc = launch(&d, a, tile_h, grid, g.stream))) return rc;
+    HIP_TRY(hipEventRecord(g.ev[1], g.stream));
+    HIP_TRY(hipMemcpyAsync(depth, g.depth.p, total * 4, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipMemcpyAsync(iters, g.iters.p, total * 4, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipMemcpyAsync(hit, g.hit.p, total, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    if (ms_total) HIP_TRY(hipEventElapsedTime(ms_total, g.ev[0], g.ev[1]));
+    if (stats) {
+        // per-frame integer reduce of the returned maps (the in-kernel block aggregates the whole batch)
+        for (int f = 0; f < nframes; ++f) {
+            RmStats& st = stats[f];
+            memset(&st, 0, sizeof st);
+            st.total_rays = n;
+            st.iter_min = n ? 0x7fffffff : 0;
+            const int32_t* it = iters + (size_t)f * n;
+            const uint8_t* h = hit + (size_t)f * n;
+            for (size_t i = 0; i < n; ++i) {
+                st.hit_count += h[i];
+                st.sum_iters += (uint64_t)it[i];
+                st.iter_max = std::max(st.iter_max, it[i]);
+                st.iter_min = std::min(st.iter_min, it[i]);
+                st.iter_hist[std::min<int32_t>(std::max<int32_t>(it[i], 0), RM_HIST_BINS - 1)] += 1;
+            }
+        }
     }
     return RM_OK;
 }

@@ -47,9 +47,20 @@ constexpr int kStatsWords = 8 + kHistBins;  // u64 words, layout below
 // device-side stats block (u64 words):
 //  [0] tile counter   [1] hit_count   [2] sum_iters   [3] iter_max   [4] 0x7fffffff - iter_min
 //  [5] rays written   [6..7] reserved [8 .. 8+kHistBins) histogram of iterations
-struct KernelArgs {
+// One frame of a launch: its camera and march configuration.  A launch renders `nframes` frames of the
+// same shape (1 for rm_render; rm_render_batch renders a whole viewpoint / budget sweep in one launch);
+// tile ids run frame-major, the output arrays are frame-major too.
+struct FrameParams {
     CameraParams cam;
     MarchCfg cfg;
+};
+
+struct KernelArgs {
+    FrameParams single;          // the frame of a one-frame launch (travels in the kernel arguments)
+    const FrameParams* frames;   // device array [nframes] for batches, nullptr for one frame
+    int32_t nframes;
+    int32_t tiles_per_frame;     // tiles_x * tiles_y
+    int32_t full;                // all frames of a launch share cfg.full
     int32_t width, height, row0, rows;
     int32_t tiles_x, tiles_y;
     int32_t refill_min;
@@ -75,10 +86,10 @@ __device__ __forceinline__ int rank_in_mask(unsigned long long m)
 
 // t_raw / final_sdf are parity-test outputs (fp64, every ray): written straight to global
 // memory when requested, never staged (they are not part of the 9 B/ray product path).
-__device__ __forceinline__ void store_raw(const KernelArgs& a, int x0, int y0, int pix, const Result& r)
+__device__ __forceinline__ void store_raw(const KernelArgs& a, size_t out0, int x0, int y0, int pix, const Result& r)
 {
     if (a.t_raw || a.final_sdf) {
-        const size_t gi = (size_t)(y0 + (pix >> 6)) * (size_t)a.width + (size_t)(x0 + (pix & 63));
+        const size_t gi = out0 + (size_t)(y0 + (pix >> 6)) * (size_t)a.width + (size_t)(x0 + (pix & 63));
         if (a.t_raw) a.t_raw[gi] = r.t;
         if (a.final_sdf) a.final_sdf[gi] = r.final_sdf;
     }
@@ -125,14 +136,19 @@ __device__ __forceinline__ void wave_lds_fence()
 
 constexpr int kSlots = 3;   // tiles a wave may have in flight: one being handed out + two draining
 
-// Tile geometry (wave-uniform): origin inside the frame slice, valid extent, image row of its first row.
+// Tile geometry (wave-uniform): frame, origin inside the frame slice, valid extent, image row of its
+// first row, element offset of the frame in the frame-major output arrays.
 struct TileGeom {
-    int x0, y0, tw, th, gy0;
+    int frame, x0, y0, tw, th, gy0;
+    size_t out0;
 };
 template <int TILE_H>
 __device__ __forceinline__ TileGeom tile_geom(const KernelArgs& a, int tile)
 {
     TileGeom g;
+    g.frame = tile / a.tiles_per_frame;
+    tile -= g.frame * a.tiles_per_frame;
+    g.out0 = (size_t)g.frame * (size_t)a.rows * (size_t)a.width;
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     g.x0 = tx * kTileW;
     g.y0 = ty * TILE_H;                                   // relative to row0
@@ -157,7 +173,7 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
     const int wave = (int)(threadIdx.x >> 6);
     float (*const s_depth)[TILE_PIX] = s_depth_all[wave];
     uint32_t (*const s_ih)[TILE_PIX] = s_ih_all[wave];
-    const int ntiles = a.tiles_x * a.tiles_y;
+    const int ntiles = a.tiles_per_frame * a.nframes;
 
     for (int b = threadIdx.x; b < kHistBins; b += blockDim.x) s_hist[b] = 0u;
     rm_load_tables<Scene>();
@@ -166,8 +182,6 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
     unsigned long long acc_hits = 0, acc_iters = 0, acc_rays = 0;
     int acc_max = 0, acc_min = 0x7fffffff;
 
-    const MarchCfg cfg = a.cfg;
-    const vec3 origin = v3(a.cam.v[0], a.cam.v[1], a.cam.v[2]);
 
     // wave-uniform scheduler state: the tiles in flight
     int slot_tile[kSlots], slot_out[kSlots];      // tile id (-1 = free) and rays handed out but not finished
@@ -176,12 +190,14 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
     int cur = 0;                                  // slot currently handing out pixels
     int pool_next = TILE_PIX;                     // next unassigned pixel id of slot `cur`
     bool more_tiles = true;                       // the global tile queue may still hold work
-    TileGeom cg = { 0, 0, 0, 0, 0 };              // geometry of slot `cur`
+    TileGeom cg = { 0, 0, 0, 0, 0, 0, 0 };        // geometry of slot `cur`
 
     // per-lane state: the ray this lane carries
     bool active = false;
     int my_slot = 0, my_pix = 0;                  // where its result goes: slot, tile-linear index y*64+x
-    vec3 dir = v3(0.0, 0.0, 0.0);
+    vec3 origin = v3(0.0, 0.0, 0.0), dir = v3(0.0, 0.0, 0.0);
+    MarchCfg cfg;                                 // of the frame this lane's ray belongs to
+    cfg.hit_threshold = 0.0; cfg.max_distance = 0.0; cfg.lipschitz = 1.0; cfg.max_iterations = 0; cfg.full = a.full;
     Strat s;
 
     for (;;) {
@@ -200,7 +216,7 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
                     if (r < g.th && col_ok) {
                         // lane == column: one 64-pixel row per store instruction
                         const int li = r * kTileW + lane;
-                        const size_t gi = (size_t)(g.y0 + r) * (size_t)a.width + (size_t)gx;
+                        const size_t gi = g.out0 + (size_t)(g.y0 + r) * (size_t)a.width + (size_t)gx;
                         const uint32_t ih = s_ih[k][li];
                         const int it = (int)(ih & 0x7fffffffu);
                         const int h = (int)(ih >> 31);
@@ -225,7 +241,8 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
                         const int brow = g.y0 + (r - 3);        // first row of this block, relative to row0
                         if (a.block_var && (lane & 7) == 0 && gx + 8 <= a.width && brow + 4 <= a.rows) {
                             // full blocks only (types.py:128-131)
-                            a.block_var[(size_t)(brow >> 2) * (size_t)(a.width >> 3) + (size_t)(gx >> 3)] = 32 * Q - S * S;
+                            a.block_var[(size_t)g.frame * (size_t)(a.rows >> 2) * (size_t)(a.width >> 3) +
+                                        (size_t)(brow >> 2) * (size_t)(a.width >> 3) + (size_t)(gx >> 3)] = 32 * Q - S * S;
                         }
                         bs = 0; bq = 0;
                     }
@@ -283,12 +300,17 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
                     if (id < TILE_PIX && px < cg.tw && py < cg.th) {
                         my_slot = cur;
                         my_pix = py * kTileW + px;
-                        vec3 o_unused;
-                        camera_ray(a.cam, a.width, a.height, cg.x0 + px, cg.gy0 + py, o_unused, dir);
+                        FrameParams fp;                                   // wave-uniform: scalar loads either way
+                        if (a.frames) fp = a.frames[cg.frame]; else fp = a.single;
+                        camera_ray(fp.cam, a.width, a.height, cg.x0 + px, cg.gy0 + py, origin, dir);
+                        cfg.hit_threshold = fp.cfg.hit_threshold;
+                        cfg.max_distance = fp.cfg.max_distance;
+                        cfg.lipschitz = fp.cfg.lipschitz;
+                        cfg.max_iterations = fp.cfg.max_iterations;
                         if (s.start(cfg)) {
                             s_depth[cur][my_pix] = s.res.hit ? (float)s.res.t : 0.0f;
                             s_ih[cur][my_pix] = (uint32_t)s.res.iters | ((uint32_t)s.res.hit << 31);
-                            store_raw(a, cg.x0, cg.y0, my_pix, s.res);
+                            store_raw(a, cg.out0, cg.x0, cg.y0, my_pix, s.res);
                         } else {
                             active = true;
                             started = true;
@@ -325,7 +347,7 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
 #pragma unroll
                     for (int k = 0; k < kSlots; ++k) t_of_slot = (k == my_slot) ? slot_tile[k] : t_of_slot;
                     const TileGeom gs = tile_geom<TILE_H>(a, t_of_slot);
-                    store_raw(a, gs.x0, gs.y0, my_pix, s.res);
+                    store_raw(a, gs.out0, gs.x0, gs.y0, my_pix, s.res);
                 }
             }
         }

@@ -187,3 +187,28 @@ def test_8k_frame_smoke(hip):
         b = _render(hip, 12, 0, w, h, row0=r0, rows=4)
         assert (a["iters"][band * 4: band * 4 + 4] == b["iters"]).all()
         assert (a["t_raw"][band * 4: band * 4 + 4].view(np.uint64) == b["t_raw"].view(np.uint64)).all()
+
+
+def test_batch_equals_single_frames(hip):
+    """rm_render_batch: 12 viewpoints x different iteration budgets / thresholds in one call, each frame
+    bit-identical to its own rm_render (cf. the reference's viewpoint and budget sweeps)."""
+    import math
+    w, h = 384, 216
+    for sid, kid in ((10, 0), (9, 10), (0, 6)):
+        cams, cfgs = [], []
+        for i in range(12):
+            ang = 2.0 * math.pi * i / 12.0
+            rad = 3.0 if sid == 10 else 5.0
+            cams.append(Camera((rad * math.sin(ang), 0.4 * math.cos(3 * ang), rad * math.cos(ang)), (0.0, 0.0, 0.0),
+                               (0.0, 1.0, 0.0), 60.0, w, h).params14())
+            cfgs.append(dict(max_iterations=[64, 128, 512][i % 3], hit_threshold=[1e-3, 1e-4][i % 2], max_distance=100.0,
+                             lipschitz=_lip(sid, kid)))
+        shape = hip.make_desc(sid, kid, cams[0], w, h)
+        out = hip.render_batch(shape, np.array(cams), cfgs)
+        assert out["ms_total"] > 0
+        for i in range(12):
+            one = hip.render(hip.make_desc(sid, kid, cams[i], w, h, **cfgs[i]))
+            assert (out["iters"][i] == one["iters"]).all() and (out["hit"][i] == one["hit"]).all(), (sid, kid, i)
+            assert (out["depth"][i].view(np.uint32) == one["depth"].view(np.uint32)).all(), (sid, kid, i)
+            assert out["stats"][i]["sum_iters"] == one["stats"]["sum_iters"]
+            assert out["stats"][i]["hit_count"] == one["stats"]["hit_count"]

@@ -56,3 +56,21 @@ elif exp == "center":
     for sid, kid in ((10, 0), (10, 4), (12, 0), (0, 0), (13, 0)):
         for gw in (512, 768, 1024, 2048):
             run(sid, kid, repeats=7, warmup=2, grid_waves=gw, tile_order_mode=2)
+elif exp == "batch":
+    import math, time
+    import numpy as np
+    w, h = 384, 384
+    for sid, kid in ((10, 0), (0, 0), (12, 0)):
+        scene = registry.SCENES[sid]
+        rad = np.linalg.norm(scene.camera_position or (0, 0, 5))
+        for n in (1, 8, 32, 64):
+            cams = [Camera((rad * math.sin(2 * math.pi * i / n), 0.3, rad * math.cos(2 * math.pi * i / n)), (0, 0, 0), (0, 1, 0), 60.0, w, h).params14() for i in range(n)]
+            shape = _native.make_desc(sid, kid, cams[0], w, h)
+            _native.render_batch(shape, np.array(cams))
+            out = _native.render_batch(shape, np.array(cams))
+            t0 = time.perf_counter()
+            for c in cams:
+                _native.render(_native.make_desc(sid, kid, c, w, h))
+            seq = (time.perf_counter() - t0) * 1e3
+            print(json.dumps(dict(scene=scene.name, frames=n, WxH=f"{w}x{h}", batch_ms=round(out["ms_total"], 3), per_frame_ms=round(out["ms_total"] / n, 3),
+                                  mrays=round(n * w * h / out["ms_total"] / 1e3, 1), sequential_wall_ms=round(seq, 2))), flush=True)
