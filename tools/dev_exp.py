@@ -74,3 +74,12 @@ elif exp == "batch":
             seq = (time.perf_counter() - t0) * 1e3
             print(json.dumps(dict(scene=scene.name, frames=n, WxH=f"{w}x{h}", batch_ms=round(out["ms_total"], 3), per_frame_ms=round(out["ms_total"] / n, 3),
                                   mrays=round(n * w * h / out["ms_total"] / 1e3, 1), sequential_wall_ms=round(seq, 2))), flush=True)
+elif exp == "prio":
+    for _ in range(2):
+        run(10, 0, repeats=9, warmup=2)
+    run(10, 0, repeats=9, warmup=2, tile_order_mode=1)
+    run(10, 0, repeats=9, warmup=2, tile_order_mode=1, grid_waves=512)
+    run(10, 0, repeats=9, warmup=2, tile_order_mode=1, grid_waves=1024)
+    run(10, 4, repeats=9, warmup=2)
+    run(12, 0, repeats=9, warmup=2)
+    run(10, 0, W=3840, H=2160, repeats=3, warmup=1)
