@@ -1,3 +1,7 @@
+"""`python -m raymarch_algo_compare_amd ...` -- the CLI of main.cli()."""
+import sys
+
 from .main import cli
 
-raise SystemExit(cli())
+if __name__ == "__main__":
+    sys.exit(cli())
