@@ -57,7 +57,7 @@ typedef struct RmFrameDesc {
     int32_t row0, rows;
     double cam[14];
     RmMarchConfig march;
-    int32_t tile_rows;   /* 0 = default (4); 4 or 8: rows per 64-pixel-wide wave tile */
+    int32_t tile_rows;   /* 0 = default; rows per 64-pixel-wide wave tile (only 4 is built) */
     int32_t refill_min;  /* 0 = default; idle lanes required before a wave refills */
     int32_t grid_waves;  /* 0 = default (fill the device); persistent wavefront count */
     /* Band-cyclic row sharding (multi-GPU load balance): local row y of this slice is image row

@@ -108,7 +108,7 @@ int check_desc(const RmFrameDesc* d)
         (!(d->band_rows > 0 && d->band_stride > 1) && d->row0 + d->rows > d->height))
         return fail(RM_E_BAD_DIMS, "bad frame slice: %dx%d rows [%d,%d)", d->width, d->height, d->row0, d->row0 + d->rows);
     if ((long long)d->width * d->height > (1ll << 31) - 1) return fail(RM_E_BAD_DIMS, "frame too large");
-    if (d->tile_rows != 0 && d->tile_rows != 4 && d->tile_rows != 8) return fail(RM_E_BAD_ARG, "tile_rows must be 0, 4 or 8");
+    if (d->tile_rows != 0 && d->tile_rows != 4) return fail(RM_E_BAD_ARG, "tile_rows must be 0 or 4");
     if (d->tile_order_mode < 0 || d->tile_order_mode > 2) return fail(RM_E_BAD_ARG, "tile_order_mode must be 0, 1 or 2");
     if (d->band_rows < 0 || d->band_stride < 0 || d->band_offset < 0) return fail(RM_E_BAD_ARG, "negative band parameter");
     if (d->band_rows > 0 && d->band_stride > 1) {

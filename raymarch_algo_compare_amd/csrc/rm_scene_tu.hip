@@ -32,7 +32,7 @@ static hipError_t render(int strategy, int tile_h, const KernelArgs& a, int grid
 {
     switch (strategy) {
 #define RM_X(id, S) \
-    case id: return tile_h == 4 ? launch_render<S, 4>(a, grid, s) : launch_render<S, 8>(a, grid, s);
+    case id: return launch_render<S, 4>(a, grid, s);
         RM_STRATEGY_LIST(RM_X)
 #undef RM_X
     }
@@ -43,7 +43,7 @@ static hipError_t occupancy(int strategy, int tile_h, int* blocks)
 {
     switch (strategy) {
 #define RM_X(id, S) \
-    case id: return tile_h == 4 ? occ_render<S, 4>(blocks) : occ_render<S, 8>(blocks);
+    case id: return occ_render<S, 4>(blocks);
         RM_STRATEGY_LIST(RM_X)
 #undef RM_X
     }

@@ -64,7 +64,7 @@ def test_row_shards_reassemble(hip, sid, kid):
 def test_deterministic_and_schedule_invariant(hip):
     for sid, kid in ((10, 0), (13, 9), (5, 5)):
         ref = _render(hip, sid, kid)
-        for kw in ({}, dict(refill_min=1), dict(refill_min=64), dict(tile_rows=8), dict(grid_waves=64), dict(grid_waves=100000),
+        for kw in ({}, dict(refill_min=1), dict(refill_min=64), dict(tile_rows=4), dict(grid_waves=64), dict(grid_waves=100000),
                    dict(tile_order_mode=1), dict(tile_order_mode=1)):   # first call records costs, second uses them
             assert _same(_render(hip, sid, kid, **kw), ref), (sid, kid, kw)
 

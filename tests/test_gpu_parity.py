@@ -89,7 +89,7 @@ def test_reference_smoke_config(hip):
         assert out["stats"]["hit_count"] > 0 and out["iters"].max() <= 100 + 9
 
 
-@pytest.mark.parametrize("tuning", [dict(tile_rows=8), dict(refill_min=1), dict(refill_min=64), dict(grid_waves=3)])
+@pytest.mark.parametrize("tuning", [dict(tile_rows=4), dict(refill_min=1), dict(refill_min=64), dict(grid_waves=3)])
 def test_schedule_invariance(hip, tuning):
     """Tile shape, refill threshold and grid size change the schedule, never the results."""
     G = golden_frames("160x120")
