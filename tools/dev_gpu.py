@@ -28,7 +28,7 @@ if __name__ == "__main__":
     cells = [(0, 0), (2, 0), (9, 0), (10, 0), (10, 4), (10, 6), (12, 0), (13, 0)]
     for sid, kid in cells:
         print(json.dumps(run(sid, kid)), flush=True)
-    for tuning in [dict(tile_rows=8), dict(refill_min=1), dict(refill_min=8), dict(refill_min=48), dict(refill_min=64),
+    for tuning in [dict(refill_min=1), dict(refill_min=8), dict(refill_min=48), dict(refill_min=64),
                    dict(grid_waves=1024), dict(grid_waves=2048), dict(grid_waves=4096), dict(grid_waves=8192)]:
         for sid, kid in [(10, 0), (0, 0)]:
             print(json.dumps(run(sid, kid, **tuning)), flush=True)
