@@ -252,6 +252,16 @@ def main():
                          "note": "write-only path, 9 B/ray; the kernel is fp64-VALU / ray-latency bound (DESIGN.md); "
                                  "store_path_* = the kernel's flush code alone at this frame size"},
         }
+        # what actually bounds the kernel: fp64 vector work.  530 fp64 flop per fractal iteration
+        # (SQ_INSTS_VALU_{FMA,ADD,MUL}_F64 of profiles/, one lane) x 1.76 fractal iterations per SDF
+        # evaluation on this view -- an estimate, reported next to the vector-fp64 peak.
+        if scene.id == 10:
+            flop = iters_step * 1.76 * 530.0
+            tf = flop / (elapsed_max / args.steps) / 1e12
+            line["valu_fp64"] = {"achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": tf / FP64_VECTOR_PEAK_TFLOPS, "flop_per_ray": flop / max(rays_step, 1.0),
+                                 "note": "estimate from counter-measured flop per fractal iteration; the frame is bound by "
+                                         "the latency of its longest rays, not by vector throughput (DESIGN.md)"}
         if temporal is not None:
             line["temporal_order"] = {
                 "value": rays_step * args.steps / temporal / 1e6 if world == 1 else None, "unit": "Mrays/s",
