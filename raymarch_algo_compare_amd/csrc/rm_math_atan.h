@@ -40,7 +40,8 @@ struct AtanK {
 RM_MATH_HD double rm_acos_sqrt_band(double x, int m)          // 0.96875 <= |x| < 1
 {
     typedef AtanK K;
-    double z = ((m > 0) ? (1.0 - x) : (x + 1.0)) * 0.5;
+    const double zp = 1.0 - x, zn = x + 1.0;
+    double z = ((m > 0) ? zp : zn) * 0.5;
     const int kz = (int)(rm_asuint64(z) >> 32);
     // powtwo[511 - (kz >> 21)] = 2^(511 - (kz >> 21)); masked so that out-of-band arguments (the
     // routine is evaluated for every x and selected afterwards) still form a finite double
@@ -61,9 +62,9 @@ RM_MATH_HD double rm_acos_sqrt_band(double x, int m)          // 0.96875 <= |x| 
     p = rm_fma(z, p, K::f2);
     p = rm_fma(z, p, K::f1);
     double pz = (p * z) * (y + cc);
-    double res_neg = ((K::hpi1 - cc) - pz) + (K::hpi - y);
-    double res_pos = (cc + pz) + y;
-    double res = (m < 0) ? res_neg : res_pos;
+    const double res_neg = ((K::hpi1 - cc) - pz) + (K::hpi - y);
+    const double res_pos = (cc + pz) + y;
+    const double res = (m < 0) ? res_neg : res_pos;
     return res + res;
 }
 
@@ -89,11 +90,13 @@ RM_MATH_HD double rm_acos(double x)
     // 1/8 <= |x| < 0.96875: unified table band
     const int i13 = (k >> 13) & 0x7f;
     int n = 11 * ((k >> 15) & 0x1f), deg = 5;
-    n = (k >= 0x3fd00000) ? 11 * ((k >> 14) & 0x3f) + 352 : n;
-    n = (k >= 0x3fe00000) ? 1056 + 12 * i13 : n;  deg = (k >= 0x3fe00000) ? 6 : deg;
-    n = (k >= 0x3fe80000) ? 992 + 13 * i13 : n;   deg = (k >= 0x3fe80000) ? 7 : deg;
-    n = (k >= 0x3fed8000) ? 884 + 14 * i13 : n;   deg = (k >= 0x3fed8000) ? 8 : deg;
-    n = (k >= 0x3fee8000) ? 768 + 15 * i13 : n;   deg = (k >= 0x3fee8000) ? 9 : deg;
+    const int n5b = 11 * ((k >> 14) & 0x3f) + 352;
+    n = (k >= 0x3fd00000) ? n5b : n;
+    const int n6 = 1056 + 12 * i13, n7 = 992 + 13 * i13, n8 = 884 + 14 * i13, n9 = 768 + 15 * i13;
+    n = (k >= 0x3fe00000) ? n6 : n;  deg = (k >= 0x3fe00000) ? 6 : deg;
+    n = (k >= 0x3fe80000) ? n7 : n;  deg = (k >= 0x3fe80000) ? 7 : deg;
+    n = (k >= 0x3fed8000) ? n8 : n;  deg = (k >= 0x3fed8000) ? 8 : deg;
+    n = (k >= 0x3fee8000) ? n9 : n;  deg = (k >= 0x3fee8000) ? 9 : deg;
     n = (n > 2568 - 13) ? 2568 - 13 : n;          // keeps the gather in bounds for out-of-band arguments
     const double* a = rm_asncs + n;
     // the whole 13-entry row is loaded unconditionally (in bounds by the clamp above), then selected:
@@ -110,8 +113,12 @@ RM_MATH_HD double rm_acos(double x)
     p = rm_fma(xx, p, a4);
     p = rm_fma(xx, p, a3);
     p = rm_fma(xx, p, a2);
-    const double c0 = (deg == 5) ? a7 : (deg == 6) ? a8 : (deg == 7) ? a9 : (deg == 8) ? a10 : a11;
-    const double cv = (deg == 5) ? a8 : (deg == 6) ? a9 : (deg == 7) ? a10 : (deg == 8) ? a11 : a12;
+    // single-level selects only: a nested ?: comes back from the compiler as a branch
+    double c0 = a11, cv = a12;
+    c0 = (deg == 8) ? a10 : c0;  cv = (deg == 8) ? a11 : cv;
+    c0 = (deg == 7) ? a9 : c0;   cv = (deg == 7) ? a10 : cv;
+    c0 = (deg == 6) ? a8 : c0;   cv = (deg == 6) ? a9 : cv;
+    c0 = (deg == 5) ? a7 : c0;   cv = (deg == 5) ? a8 : cv;
     p = rm_fma(xx * xx, p, c0);
     const double t = rm_fma(xx, a1, p);
     const double yb = pos ? (K::hpi - cv) : (cv + K::hpi);
@@ -124,7 +131,10 @@ RM_MATH_HD double rm_acos(double x)
     // the routine is one straight-line block (the z argument is clamped to stay in the table)
     const double res_sqrt = rm_acos_sqrt_band(x, m);
     res = (k >= 0x3fef0000) ? res_sqrt : res;
-    res = (k >= 0x3ff00000) ? ((k == 0x3ff00000 && (uint32_t)bits == 0) ? (pos ? 0.0 : K::opi) : __builtin_nan("")) : res;
+    const double at_one = pos ? 0.0 : K::opi;                                    // |x| == 1
+    const bool is_one = (k == 0x3ff00000) & ((uint32_t)bits == 0);
+    const double beyond = is_one ? at_one : __builtin_nan("");                   // |x| > 1 or NaN: invalid
+    res = (k >= 0x3ff00000) ? beyond : res;
     return res;
 }
 
@@ -153,9 +163,9 @@ RM_MATH_HD double rm_atan2(double y, double x)
     const int de = (int)(uy & 0x7ff00000u) - (int)(ux & 0x7ff00000u);
 
     double ax = rm_fabs(x), ay = rm_fabs(y);
-    const double up = (ax < 0x1p-500 || ay < 0x1p-500) ? 0x1p500 : 1.0;
+    const double up = ((ax < 0x1p-500) | (ay < 0x1p-500)) ? 0x1p500 : 1.0;
     ax *= up; ay *= up;
-    const double dn = (ax > 0x1p500 || ay > 0x1p500) ? 0x1p-500 : 1.0;
+    const double dn = ((ax > 0x1p500) | (ay > 0x1p500)) ? 0x1p-500 : 1.0;
     ax *= dn; ay *= dn;
 
     const bool y_lt_x = ay < ax;
@@ -165,10 +175,10 @@ RM_MATH_HD double rm_atan2(double y, double x)
     const double du = ((num - vq) - rm_fma(den, u, -vq)) / den;
 
     const bool xpos = x > 0.0;
-    const bool case_i = xpos && y_lt_x;
+    const bool case_i = xpos & y_lt_x;
     // cases (ii) x>0,|x|<=|y|: pi/2 - atan;  (iii) x<0,|x|<|y|: pi/2 + atan;  (iv) x<0,|y|<=|x|: pi - atan
-    const bool case_iv = !xpos && !(ax < ay);
-    const bool plus = !xpos && (ax < ay);
+    const bool case_iv = !xpos & !(ax < ay);
+    const bool plus = !xpos & (ax < ay);
     const double B = case_iv ? K::opi : K::hpi, B1 = case_iv ? K::opi1 : K::hpi1;
 
     // series forms (u < 1/16)
@@ -206,14 +216,17 @@ RM_MATH_HD double rm_atan2(double y, double x)
     const double z_ot = (B + (plus ? c1 : -c1)) + rm_fma(plus ? vo : -vo, po, B1);
 
     const bool small = u < 0.0625;
-    double z = case_i ? (small ? z_is : z_it) : (small ? z_os : z_ot);
+    const double z_i = small ? z_is : z_it, z_o = small ? z_os : z_ot;
+    double z = case_i ? z_i : z_o;
     // special operands (e_atan2.c:66-133), resolved by selects in the reference's priority order
     const bool xneg = (ux & 0x80000000u) != 0;
-    z = (de <= -59768832) ? (xpos ? u : K::opi) : z;             // |y/x| tiny: y/x itself, or pi
+    const double z_tiny = xpos ? u : K::opi;
+    z = (de <= -59768832) ? z_tiny : z;                          // |y/x| tiny: y/x itself, or pi
     z = (de >= 59768832) ? K::hpi : z;                           // |y/x| huge
     z = (x == 0.0) ? K::hpi : z;                                 // x = +-0, y != 0
-    z = (y == 0.0) ? (xneg ? K::opi : 0.0) : z;                  // y = +-0: +-0 or +-pi by the sign of x
-    const bool nonfinite = (ux & 0x7ff00000u) == 0x7ff00000u || (uy & 0x7ff00000u) == 0x7ff00000u;
+    const double z_y0 = xneg ? K::opi : 0.0;
+    z = (y == 0.0) ? z_y0 : z;                                   // y = +-0: +-0 or +-pi by the sign of x
+    const bool nonfinite = ((ux & 0x7ff00000u) == 0x7ff00000u) | ((uy & 0x7ff00000u) == 0x7ff00000u);
     z = nonfinite ? __builtin_nan("") : z;                       // inf / nan operands: unclaimed
     return __builtin_copysign(z, y);
 }

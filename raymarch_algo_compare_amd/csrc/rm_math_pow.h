@@ -106,8 +106,10 @@ RM_MATH_HD double rm_pow_exp_inline(double ehi, double elo)
     double res = rm_fma(tmp, scale, scale);
     // |y log x| < 2^-54: 1 + ehi;  |y log x| >= 512: the result leaves the normal range
     uint32_t abstop = (uint32_t)(rm_asuint64(ehi) >> 52) & 0x7ff;
-    res = (abstop < 0x3c9) ? 1.0 + ehi : res;
-    res = (abstop >= 0x409) ? ((ehi < 0.0) ? 0.0 : __builtin_inf()) : res;
+    const double tiny = 1.0 + ehi;
+    const double out_of_range = (ehi < 0.0) ? 0.0 : __builtin_inf();
+    res = (abstop < 0x3c9) ? tiny : res;
+    res = (abstop >= 0x409) ? out_of_range : res;
     return res;
 }
 
@@ -115,7 +117,7 @@ RM_MATH_HD double rm_pow_fix_special(double x, double res)
 {
     res = (x == 0.0) ? 0.0 : res;                       // pow(+0, y > 0) = +0
     res = (x == __builtin_inf()) ? x : res;             // pow(+inf, y > 0) = +inf
-    res = (x != x || x < 0.0) ? __builtin_nan("") : res;    // NaN in -> NaN; negative base unclaimed
+    res = ((x != x) | (x < 0.0)) ? __builtin_nan("") : res;  // NaN in -> NaN; negative base unclaimed
     return res;
 }
 

@@ -120,9 +120,10 @@ RM_MATH_HD void rm_sincos(double x, double* sin_out, double* cos_out)
     const double da2 = (tt - a2) + K::hp1;
 
     const bool r1 = k < 0x3feb6000u;
-    const bool r2 = !r1 && k < 0x400368fdu;
-    const double aS = r1 ? x : (r2 ? a2 : b), daS = r1 ? 0.0 : (r2 ? da2 : db);
-    const double aC = r1 ? x : (r2 ? tt : b), daC = r1 ? 0.0 : (r2 ? K::hp1 : db);
+    const bool r2 = !r1 & (k < 0x400368fdu);
+    // single-level selects only (a nested ?: comes back from the compiler as a branch)
+    double aS = r2 ? a2 : b, daS = r2 ? da2 : db, aC = r2 ? tt : b, daC = r2 ? K::hp1 : db;
+    aS = r1 ? x : aS; daS = r1 ? 0.0 : daS; aC = r1 ? x : aC; daC = r1 ? 0.0 : daC;
     const double dS = rm_do_sin(aS, daS);
     const double dC = rm_do_cos(aC, daC);
 
@@ -132,8 +133,10 @@ RM_MATH_HD void rm_sincos(double x, double* sin_out, double* cos_out)
     s3 = (n & 2u) ? -s3 : s3;
     double c3 = (m & 1u) ? dC : dS;
     c3 = (m & 2u) ? -c3 : c3;
-    double s = r1 ? dS : (r2 ? __builtin_copysign(dC, x) : s3);
-    double c = r1 ? dC : (r2 ? dS : c3);
+    const double s2 = __builtin_copysign(dC, x);
+    double s = r2 ? s2 : s3, c = r2 ? dS : c3;
+    s = r1 ? dS : s;
+    c = r1 ? dC : c;
     s = (k < 0x3e500000u) ? x : s;                      // |x| < 2^-26
     c = (k < 0x3e400000u) ? 1.0 : c;                    // |x| < 2^-27
     const double bad = __builtin_nan("");                // inf / nan -> nan; __branred range unclaimed
