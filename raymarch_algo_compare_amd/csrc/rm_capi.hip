@@ -8,7 +8,6 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -155,7 +154,6 @@ int make_args(const RmFrameDesc* d, float* depth, int32_t* iters, uint8_t* hit, 
     const bool expensive = d->scene_id == 10 || d->scene_id == 14 || d->scene_id == 15 || d->scene_id == 16 || d->scene_id == 19;
     a->refill_min = d->refill_min > 0 ? d->refill_min : (expensive ? 8 : 24);
     a->hist_bins = rm::kHistBins;
-    if (const char* e = getenv("RM_DEBUG_DYN_LDS")) a->dyn_lds = atoi(e);   // developer knob: force fewer workgroups per CU
     if (d->band_rows > 0 && d->band_stride > 1) {
         a->band_rows = d->band_rows; a->band_stride = d->band_stride; a->band_offset = d->band_offset;
     }

@@ -73,7 +73,6 @@ struct KernelArgs {
     double* final_sdf;        // optional: MarchResult.final_sdf (needs cfg.full)
     long long* block_var;     // optional: (rows/4) x (width/8) variance numerators 32*sum(x^2)-sum(x)^2
     unsigned long long* stats;
-    int32_t dyn_lds;            // extra dynamic LDS bytes per workgroup (occupancy control: 0 = none)
     const int32_t* tile_order;  // optional: permutation of the tile ids (longest-first schedule)
     int32_t* tile_cost;         // optional: per tile, the largest iteration count of its rays
 };

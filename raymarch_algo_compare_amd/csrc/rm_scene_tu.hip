@@ -18,7 +18,7 @@ using SceneT = SceneById<RM_SCENE_ID>::type;
 template <class Strat, int TH>
 static hipError_t launch_render(const KernelArgs& a, int grid, hipStream_t s)
 {
-    hipLaunchKernelGGL((render_kernel<SceneT, Strat, TH>), dim3(grid), dim3(64 * kWavesPerWG), (size_t)a.dyn_lds, s, a);
+    hipLaunchKernelGGL((render_kernel<SceneT, Strat, TH>), dim3(grid), dim3(64 * kWavesPerWG), 0, s, a);
     return hipGetLastError();
 }
 
