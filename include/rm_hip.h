@@ -73,7 +73,11 @@ typedef struct RmFrameDesc {
      * identical in either mode; only the schedule changes).  Falls back to 0 when no matching
      * previous frame exists. */
     int32_t tile_order_mode;
-    int32_t reserved;
+    /* Scenes whose SDF is a data-dependent loop (Mandelbulb, catalog.py:266-293).  0 = default
+     * (library's choice, currently 2); 1 = a whole SDF evaluation per wave turn; 2 = one trip of the
+     * SDF loop per wave turn, lanes advance to their next evaluation independently.  Results are
+     * identical in either mode; ignored for every other scene. */
+    int32_t eval_mode;
 } RmFrameDesc;
 
 /* Frame reduce computed in-kernel (the integer part of RayMarchStats.compute, core/types.py:77-137). */

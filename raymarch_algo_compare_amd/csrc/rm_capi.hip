@@ -109,6 +109,7 @@ int check_desc(const RmFrameDesc* d)
     if ((long long)d->width * d->height > (1ll << 31) - 1) return fail(RM_E_BAD_DIMS, "frame too large");
     if (d->tile_rows != 0 && d->tile_rows != 4) return fail(RM_E_BAD_ARG, "tile_rows must be 0 or 4");
     if (d->tile_order_mode < 0 || d->tile_order_mode > 2) return fail(RM_E_BAD_ARG, "tile_order_mode must be 0, 1 or 2");
+    if (d->eval_mode < 0 || d->eval_mode > 2) return fail(RM_E_BAD_ARG, "eval_mode must be 0, 1 or 2");
     if (d->band_rows < 0 || d->band_stride < 0 || d->band_offset < 0) return fail(RM_E_BAD_ARG, "negative band parameter");
     if (d->band_rows > 0 && d->band_stride > 1) {
         const int th = d->tile_rows ? d->tile_rows : 4;
@@ -154,6 +155,7 @@ int make_args(const RmFrameDesc* d, float* depth, int32_t* iters, uint8_t* hit, 
     const bool expensive = d->scene_id == 10 || d->scene_id == 14 || d->scene_id == 15 || d->scene_id == 16 || d->scene_id == 19;
     a->refill_min = d->refill_min > 0 ? d->refill_min : (expensive ? 8 : 24);
     a->hist_bins = rm::kHistBins;
+    a->interleave = d->eval_mode != 1;
     if (d->band_rows > 0 && d->band_stride > 1) {
         a->band_rows = d->band_rows; a->band_stride = d->band_stride; a->band_offset = d->band_offset;
     }
@@ -168,7 +170,7 @@ int make_args(const RmFrameDesc* d, float* depth, int32_t* iters, uint8_t* hit, 
         wgs = (d->grid_waves + rm::kWavesPerWG - 1) / rm::kWavesPerWG;
     } else {
         int per_cu = 0;
-        hipError_t e = rm::scene(d->scene_id)->occupancy(d->strategy_id, th, &per_cu);
+        hipError_t e = rm::scene(d->scene_id)->occupancy(d->strategy_id, th, a->interleave, &per_cu);
         if (e != hipSuccess || per_cu <= 0) per_cu = 2;
         wgs = (long long)g.prop.multiProcessorCount * per_cu;
     }
@@ -579,7 +581,7 @@ int rm_render_batch(const RmFrameDesc* shape, int32_t nframes, const double* cam
     if (d.grid_waves <= 0) {      // the batch is one big launch: size the persistent grid for all its tiles
         const long long ntiles = (long long)a.tiles_per_frame * nframes;
         int per_cu = 0;
-        if (rm::scene(d.scene_id)->occupancy(d.strategy_id, tile_h, &per_cu) != hipSuccess || per_cu <= 0) per_cu = 2;
+        if (rm::scene(d.scene_id)->occupancy(d.strategy_id, tile_h, a.interleave, &per_cu) != hipSuccess || per_cu <= 0) per_cu = 2;
         grid = (int)std::max<long long>(1, std::min<long long>((long long)g.prop.multiProcessorCount * per_cu,
                                                                 (ntiles + rm::kWavesPerWG - 1) / rm::kWavesPerWG));
     }

@@ -64,6 +64,7 @@ struct KernelArgs {
     int32_t width, height, row0, rows;
     int32_t tiles_x, tiles_y;
     int32_t refill_min;
+    int32_t interleave;          // scenes with a resumable SDF: one trip of the SDF loop per turn (see render_kernel)
     int32_t hist_bins;
     int32_t band_rows, band_stride, band_offset;   // band-cyclic row map (band_rows == 0: identity)        // clamp for the LDS histogram (<= kHistBins)
     float* depth;             // rows*width, t if hit else 0 (types.py:93), fp32
@@ -159,9 +160,20 @@ __device__ __forceinline__ TileGeom tile_geom(const KernelArgs& a, int tile)
     return g;
 }
 
-template <class Scene, class Strat, int TILE_H>
+// Per-lane evaluation state of the trip-interleaved mode (empty for scenes without a resumable SDF).
+struct NoEval {};
+template <class Scene, bool ITER> struct EvalOf { using type = NoEval; };
+template <class Scene> struct EvalOf<Scene, true> { using type = typename Scene::Eval; };
+
+// INTERLEAVE (scenes with a resumable SDF only): a turn of the wave loop runs ONE trip of the SDF's
+// inner loop for every lane instead of a whole evaluation; a lane whose value is ready consumes it
+// (strategy step) and begins its next evaluation while its neighbours are still iterating.  The
+// lanes of a wavefront rarely need the same trip count (Mandelbulb: 1..8, mean 1.8), so a whole
+// evaluation per turn leaves more than half of the lanes idle inside the SDF loop.
+template <class Scene, class Strat, int TILE_H, bool INTERLEAVE>
 __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelArgs a)
 {
+    static_assert(!INTERLEAVE || SceneIterative<Scene>::value, "INTERLEAVE needs Scene::Eval");
     constexpr int TILE_PIX = kTileW * TILE_H;
     // per wave and tile slot: fp32 depth + (iterations | hit << 31) of every pixel of the tile
     __shared__ float s_depth_all[kWavesPerWG][kSlots][TILE_PIX];
@@ -198,8 +210,15 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
     MarchCfg cfg;                                 // of the frame this lane's ray belongs to
     cfg.hit_threshold = 0.0; cfg.max_distance = 0.0; cfg.lipschitz = 1.0; cfg.max_iterations = 0; cfg.full = a.full;
     Strat s;
+    typename EvalOf<Scene, INTERLEAVE>::type ev;  // INTERLEAVE: the SDF evaluation in flight
+    bool ready = false;                           // INTERLEAVE: its value can be consumed
+    // wave-uniform: the scheduler (flush + refill) has something to look at -- a ray finished, a
+    // refill handed out pixels or opened a tile.  Otherwise a turn goes straight to the SDF.
+    bool dirty = true;
 
     for (;;) {
+        if (dirty) {
+        dirty = false;
         // ---- 1. flush every tile whose rays have all finished (and whose pool is handed out) -----
 #pragma unroll
         for (int k = 0; k < kSlots; ++k) {
@@ -276,6 +295,7 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
                         if (a.tile_order) tile = __builtin_amdgcn_readfirstlane(a.tile_order[tile]);
                         cur = f;
                         pool_next = 0;
+                        dirty = true;
                         cg = tile_geom<TILE_H>(a, tile);
 #pragma unroll
                         for (int k = 0; k < kSlots; ++k) {
@@ -313,6 +333,9 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
                         } else {
                             active = true;
                             started = true;
+                            if constexpr (INTERLEAVE) {
+                                ready = Scene::begin(ev, origin + dir * s.te);   // ray.py:15-17
+                            }
                         }
                     }
                 }
@@ -320,8 +343,10 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
 #pragma unroll
                 for (int k = 0; k < kSlots; ++k) slot_out[k] += (k == cur) ? nstarted : 0;
                 pool_next += nidle;
+                dirty = true;
             }
         }
+        }   // dirty
 
         // ---- 3. exit / idle turn ---------------------------------------------------------------------
         if (!__any(active)) {
@@ -329,13 +354,19 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
 #pragma unroll
             for (int k = 0; k < kSlots; ++k) in_flight = in_flight || (slot_tile[k] >= 0);
             if (!more_tiles && !in_flight) break;     // wave-uniform; nothing left anywhere
+            dirty = true;
             continue;                                 // a flush or a refill makes progress next turn
         }
 
-        // ---- 4. one SDF evaluation for every live ray ----------------------------------------------
+        // ---- 4. one SDF evaluation (INTERLEAVE: one trip of it) for every live ray -----------------
         bool fin = false;
-        if (active) {
-            const double d = Scene::sdf(origin + dir * s.te);   // ray.py:15-17
+        bool consume = active;
+        if constexpr (INTERLEAVE) consume = active && ready;
+        if (!INTERLEAVE || __any(consume)) {
+        if (consume) {
+            double d;
+            if constexpr (INTERLEAVE) d = Scene::value(ev);
+            else d = Scene::sdf(origin + dir * s.te);   // ray.py:15-17
             if (s.step(d, cfg)) {
                 active = false;
                 fin = true;
@@ -348,11 +379,18 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
                     const TileGeom gs = tile_geom<TILE_H>(a, t_of_slot);
                     store_raw(a, gs.out0, gs.x0, gs.y0, my_pix, s.res);
                 }
+            } else if constexpr (INTERLEAVE) {
+                ready = Scene::begin(ev, origin + dir * s.te);   // ray.py:15-17
             }
         }
         if (__any(fin)) {
 #pragma unroll
             for (int k = 0; k < kSlots; ++k) slot_out[k] -= __popcll(__ballot(fin && my_slot == k));
+            dirty = true;
+        }
+        }
+        if constexpr (INTERLEAVE) {
+            if (active && !ready) ready = Scene::trip(ev);
         }
     }
 
@@ -404,7 +442,7 @@ __global__ void march_rays_kernel(MarchCfg cfg, const double* __restrict__ origi
 // Per-scene launch table, filled by rm_scene_tu.hip (one translation unit per scene).
 struct SceneLaunchers {
     hipError_t (*render)(int strategy, int tile_h, const KernelArgs& a, int grid, hipStream_t s);
-    hipError_t (*occupancy)(int strategy, int tile_h, int* blocks_per_cu);
+    hipError_t (*occupancy)(int strategy, int tile_h, int interleave, int* blocks_per_cu);
     hipError_t (*sdf_eval)(const double* xyz, size_t n, double* out, hipStream_t s);
     hipError_t (*march_rays)(int strategy, const MarchCfg& cfg, const double* o, const double* d, size_t n,
                              uint8_t* hit, double* t, int32_t* iters, double* fs, hipStream_t s);

@@ -15,17 +15,24 @@ RM_SCENE_LIST(RM_X)
 #undef RM_X
 using SceneT = SceneById<RM_SCENE_ID>::type;
 
+constexpr bool kIter = SceneIterative<SceneT>::value;
+
 template <class Strat, int TH>
 static hipError_t launch_render(const KernelArgs& a, int grid, hipStream_t s)
 {
-    hipLaunchKernelGGL((render_kernel<SceneT, Strat, TH>), dim3(grid), dim3(64 * kWavesPerWG), 0, s, a);
+    if (kIter && a.interleave)
+        hipLaunchKernelGGL((render_kernel<SceneT, Strat, TH, kIter>), dim3(grid), dim3(64 * kWavesPerWG), 0, s, a);
+    else
+        hipLaunchKernelGGL((render_kernel<SceneT, Strat, TH, false>), dim3(grid), dim3(64 * kWavesPerWG), 0, s, a);
     return hipGetLastError();
 }
 
 template <class Strat, int TH>
-static hipError_t occ_render(int* blocks)
+static hipError_t occ_render(int interleave, int* blocks)
 {
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, render_kernel<SceneT, Strat, TH>, 64 * kWavesPerWG, 0);
+    if (kIter && interleave)
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, render_kernel<SceneT, Strat, TH, kIter>, 64 * kWavesPerWG, 0);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, render_kernel<SceneT, Strat, TH, false>, 64 * kWavesPerWG, 0);
 }
 
 static hipError_t render(int strategy, int tile_h, const KernelArgs& a, int grid, hipStream_t s)
@@ -39,11 +46,11 @@ static hipError_t render(int strategy, int tile_h, const KernelArgs& a, int grid
     return hipErrorInvalidValue;
 }
 
-static hipError_t occupancy(int strategy, int tile_h, int* blocks)
+static hipError_t occupancy(int strategy, int tile_h, int interleave, int* blocks)
 {
     switch (strategy) {
 #define RM_X(id, S) \
-    case id: return occ_render<S, 4>(blocks);
+    case id: return occ_render<S, 4>(interleave, blocks);
         RM_STRATEGY_LIST(RM_X)
 #undef RM_X
     }

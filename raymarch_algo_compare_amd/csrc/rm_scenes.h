@@ -13,6 +13,9 @@ namespace rm {
 // Every scene needs the pow tables: camera normalisation and length() are `** 0.5`.
 enum : unsigned { TB_POW = 1u, TB_SINCOS = 2u, TB_ACOS = 4u, TB_ATAN = 8u, TB_LOG = 16u };
 template <class Scene> struct SceneTables { static constexpr unsigned value = TB_POW; };
+// Scenes whose SDF is a data-dependent loop expose it as a resumable evaluation (Scene::Eval with
+// begin / trip / value); the render kernel then interleaves trips of different evaluations.
+template <class Scene> struct SceneIterative { static constexpr bool value = false; };
 
 // ---- scenes/primitives.py -----------------------------------------------------
 
@@ -138,29 +141,59 @@ struct SceneMenger {                                                            
     }
 };
 struct SceneMandelbulb {                                                                 // :266-293 (power 8, 8 iterations)
-    static RM_HD double sdf(vec3 p)
+    // The SDF is a data-dependent loop (1..8 trips, 1.8 on average on the default view, the lanes of a
+    // wavefront rarely agree).  It is written as a resumable evaluation -- begin / trip / value -- so the
+    // render kernel can run ONE trip per turn for every lane and let a lane whose value is ready go on
+    // to its next evaluation (rm_kernels.h); sdf() below is the same three pieces run to completion.
+    struct Eval {
+        vec3 p, z;
+        double dr, r;
+        int32_t i;
+    };
+    // start of an evaluation: the first `r = z.length(); if r > bailout: break` (:272-274).
+    // true when the value is ready at once (the point lies outside the bailout radius)
+    static RM_HD bool begin(Eval& e, vec3 p)
+    {
+        e.p = p; e.z = p; e.dr = 1.0; e.i = 0;
+        e.r = length(p);
+        return e.r > 4.0;
+    }
+    // the body of one trip of `for i in range(8)` (:276-290) followed by the loop test and the next
+    // trip's length / bailout test; needs r <= 4 and i < 8.  true when the loop has ended.  The loop
+    // is rotated (test at the bottom) so that every trip a lane takes is a full update: an
+    // evaluation with u updates costs u trips, none for a point outside the bailout radius.
+    static RM_HD bool trip(Eval& e)
     {
         const double power = 8.0;
-        vec3 z = p;
-        double dr = 1.0, r = 0.0;
-        for (int i = 0; i < 8; ++i) {
-            r = length(z);
-            if (r > 4.0) break;
-            // acos / atan2 / the two pows are independent of one another, as are the two sincos
-            // pairs: written back to back (all branch-free) so their dependency chains interleave.
-            double theta = rm_acos(py_max(-1.0, py_min(1.0, z.z / py_max(r, 1e-12))));
-            double phi = rm_atan2(z.y, z.x);
-            double r7, zr;
-            rm_pow2(r, power - 1.0, power, &r7, &zr);       // r ** 7.0 and r ** 8.0 share log(r)
-            dr = r7 * power * dr + 1.0;
-            theta *= power;
-            phi *= power;
-            double st, ct, sp, cp;
-            rm_sincos(theta, &st, &ct);
-            rm_sincos(phi, &sp, &cp);
-            z = v3(zr * st * cp, zr * st * sp, zr * ct) + p;
-        }
-        return 0.5 * rm_log(py_max(r, 1e-12)) * r / py_max(dr, 1e-12);
+        const vec3 z = e.z;
+        const double r = e.r;
+        // acos / atan2 / the two pows are independent of one another, as are the two sincos
+        // pairs: written back to back (all branch-free) so their dependency chains interleave.
+        double theta = rm_acos(py_max(-1.0, py_min(1.0, z.z / py_max(r, 1e-12))));
+        double phi = rm_atan2(z.y, z.x);
+        double r7, zr;
+        rm_pow2(r, power - 1.0, power, &r7, &zr);       // r ** 7.0 and r ** 8.0 share log(r)
+        e.dr = r7 * power * e.dr + 1.0;
+        theta *= power;
+        phi *= power;
+        double st, ct, sp, cp;
+        rm_sincos(theta, &st, &ct);
+        rm_sincos(phi, &sp, &cp);
+        e.z = v3(zr * st * cp, zr * st * sp, zr * ct) + e.p;
+        if (++e.i >= 8) return true;                    // r keeps the length measured before this update
+        e.r = length(e.z);
+        return e.r > 4.0;
+    }
+    static RM_HD double value(const Eval& e)
+    {
+        return 0.5 * rm_log(py_max(e.r, 1e-12)) * e.r / py_max(e.dr, 1e-12);
+    }
+    static RM_HD double sdf(vec3 p)
+    {
+        Eval e;
+        bool done = begin(e, p);
+        while (!done) done = trip(e);
+        return value(e);
     }
 };
 struct SceneBadLipschitz {                                                               // :320-321
@@ -289,6 +322,7 @@ struct SceneMetaballs {                                                         
 };
 
 template <> struct SceneTables<SceneMandelbulb> { static constexpr unsigned value = TB_POW | TB_SINCOS | TB_ACOS | TB_ATAN | TB_LOG; };
+template <> struct SceneIterative<SceneMandelbulb> { static constexpr bool value = true; };
 template <> struct SceneTables<SceneGyroid> { static constexpr unsigned value = TB_POW | TB_SINCOS; };
 
 #define RM_NUM_SCENES 20

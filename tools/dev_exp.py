@@ -31,6 +31,21 @@ if exp == "budget":
         run(10, 0, grid_waves=gw, refill_min=8)
     for W, H in ((960, 540), (3840, 2160), (7680, 4320)):
         run(10, 0, W=W, H=H, repeats=3, warmup=1)
+elif exp == "interleave":
+    for em in (1, 2):
+        run(10, 0, repeats=7, warmup=2, eval_mode=em)
+        run(10, 0, repeats=7, warmup=2, eval_mode=em, tile_order_mode=1, grid_waves=512)
+        run(10, 0, repeats=7, warmup=2, eval_mode=em, tile_order_mode=1, grid_waves=1024)
+        run(10, 0, repeats=7, warmup=2, eval_mode=em, tile_order_mode=1)
+        for mi in (32, 64):
+            run(10, 0, repeats=5, warmup=2, eval_mode=em, max_iterations=mi)
+        for kid in (4, 6, 10):
+            run(10, kid, repeats=5, warmup=2, eval_mode=em)
+        run(10, 0, W=3840, H=2160, repeats=3, warmup=1, eval_mode=em)
+        run(10, 0, W=7680, H=4320, repeats=3, warmup=1, eval_mode=em)
+    for rmn in (1, 4, 16, 32):
+        run(10, 0, repeats=5, warmup=2, eval_mode=2, refill_min=rmn)
+        run(10, 0, W=3840, H=2160, repeats=3, warmup=1, eval_mode=2, refill_min=rmn)
 elif exp == "one":
     run(int(sys.argv[2]), int(sys.argv[3]), repeats=int(sys.argv[4]) if len(sys.argv) > 4 else 5)
 elif exp == "matrix":
