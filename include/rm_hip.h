@@ -78,6 +78,15 @@ typedef struct RmFrameDesc {
      * SDF loop per wave turn, lanes advance to their next evaluation independently.  Results are
      * identical in either mode; ignored for every other scene. */
     int32_t eval_mode;
+    /* Long-ray suspension.  A frame cannot finish before its longest ray, and that ray only starts
+     * when the tile order reaches its pixel.  Pass 1 parks every ray still marching after
+     * suspend_after[0] trips of its strategy loop and goes on with fresh pixels; pass 2 restarts all
+     * parked rays at once (dense wavefronts of long rays) and parks those beyond suspend_after[1]
+     * trips for a last sparse pass.  A parked ray continues from its saved strategy state, so results
+     * are identical with or without suspension.  Per entry: 0 = library default, < 0 = off. */
+    int32_t suspend_after[2];
+    int32_t resume_grid;   /* 0 = default; workgroups of the resume passes (developer knob) */
+    int32_t reserved;
 } RmFrameDesc;
 
 /* Frame reduce computed in-kernel (the integer part of RayMarchStats.compute, core/types.py:77-137). */

@@ -49,7 +49,9 @@ class RmFrameDesc(ctypes.Structure):
                 ("tile_rows", ctypes.c_int32), ("refill_min", ctypes.c_int32),
                 ("grid_waves", ctypes.c_int32), ("band_rows", ctypes.c_int32),
                 ("band_stride", ctypes.c_int32), ("band_offset", ctypes.c_int32),
-                ("tile_order_mode", ctypes.c_int32), ("eval_mode", ctypes.c_int32)]
+                ("tile_order_mode", ctypes.c_int32), ("eval_mode", ctypes.c_int32),
+                ("suspend_after", ctypes.c_int32 * 2),
+                ("resume_grid", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class RmStats(ctypes.Structure):
@@ -148,7 +150,8 @@ def device_info() -> dict:
 
 def make_desc(scene_id, strategy_id, cam14, width, height, row0=0, rows=None, max_iterations=512,
               hit_threshold=1e-4, max_distance=100.0, lipschitz=1.0, full=False, tile_rows=0, refill_min=0,
-              grid_waves=0, band_rows=0, band_stride=0, band_offset=0, tile_order_mode=0, eval_mode=0) -> RmFrameDesc:
+              grid_waves=0, band_rows=0, band_stride=0, band_offset=0, tile_order_mode=0, eval_mode=0,
+              suspend_after=(0, 0), resume_grid=0, reserved=0) -> RmFrameDesc:
     d = RmFrameDesc()
     d.scene_id, d.strategy_id = int(scene_id), int(strategy_id)
     d.width, d.height = int(width), int(height)
@@ -168,6 +171,9 @@ def make_desc(scene_id, strategy_id, cam14, width, height, row0=0, rows=None, ma
     d.band_rows, d.band_stride, d.band_offset = int(band_rows), int(band_stride), int(band_offset)
     d.tile_order_mode = int(tile_order_mode)
     d.eval_mode = int(eval_mode)
+    d.suspend_after[0], d.suspend_after[1] = int(suspend_after[0]), int(suspend_after[1])
+    d.resume_grid = int(resume_grid)
+    d.reserved = int(reserved)
     return d
 
 

@@ -78,7 +78,7 @@ struct State {
     int device = -1;
     hipStream_t stream = nullptr;
     hipDeviceProp_t prop;
-    Buf stats, depth, iters, hit, traw, fs, bvar, in0, in1, out0, out1, out2, out3, tcost, torder;
+    Buf stats, depth, iters, hit, traw, fs, bvar, in0, in1, out0, out1, out2, out3, tcost, torder, queue[rm::kQueues];
     // shape of the frame whose per-tile costs sit in `tcost` (tile_order_mode 1 needs a match)
     long long cost_key[10] = { -1 };
     bool cost_valid = false;
@@ -214,6 +214,43 @@ __global__ void center_cost_kernel(int32_t* __restrict__ cost, int tiles_x, int 
     cost[t] = max(0, 1023 - (int)(r * 256.0f));
 }
 
+// 8x4-block variance numerators 32*sum(x^2) - sum(x)^2 of the finished iteration map (core/types.py:125-133),
+// one thread per full block: used instead of the in-flush reduction when rays were parked (their
+// pixels are not in the tile when it is flushed).
+__global__ void block_var_kernel(const int32_t* __restrict__ iters, int width, int rows, int nframes,
+                                 long long* __restrict__ out)
+{
+    const int bw = width >> 3, bh = rows >> 2;
+    const long long n = (long long)bw * bh * nframes;
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n) return;
+    const int f = (int)(b / ((long long)bw * bh));
+    const int r = (int)(b - (long long)f * bw * bh);
+    const int by = r / bw, bx = r - by * bw;
+    const int32_t* p = iters + (size_t)f * (size_t)rows * (size_t)width + (size_t)(by * 4) * (size_t)width + (size_t)(bx * 8);
+    long long S = 0, Q = 0;
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            const long long v = p[(size_t)y * (size_t)width + x];
+            S += v; Q += v * v;
+        }
+    out[b] = 32 * Q - S * S;
+}
+
+constexpr long long kQueueCapMax = 1ll << 22;   // entries per suspended-ray queue (a full queue leaves rays in place)
+
+// Trip budgets of pass 1 / pass 2 (0 = that pass does not park).  desc->suspend_after: 0 = library
+// default, < 0 = off, > 0 = explicit.
+void suspend_levels(const RmFrameDesc* d, int ntiles, int* park)
+{
+    park[0] = d->suspend_after[0] > 0 ? d->suspend_after[0] : 0;
+    park[1] = d->suspend_after[1] > 0 ? d->suspend_after[1] : 0;
+    if (park[0] == 0) park[1] = 0;
+    if (park[1] > 0 && park[1] <= park[0]) park[1] = 0;
+}
+
 void frame_key(const RmFrameDesc* d, int tile_h, long long* k)
 {
     k[0] = d->scene_id; k[1] = d->strategy_id; k[2] = d->width; k[3] = d->height; k[4] = d->row0; k[5] = d->rows;
@@ -250,7 +287,50 @@ int launch(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, hipStre
         HIP_TRY(hipGetLastError());
         a.tile_order = (const int32_t*)g.torder.p;
     }
+    // long-ray suspension: pass 1 parks rays beyond suspend_after[0] trips, pass 2 restarts them all at
+    // once and parks those beyond suspend_after[1], pass 3 finishes the few that remain
+    int park[2];
+    suspend_levels(d, ntiles, park);
+    long long* const block_var = a.block_var;
+    if (park[0] > 0) {
+        const long long total = (long long)a.rows * a.width * a.nframes;
+        const long long cap = std::min<long long>(total, kQueueCapMax);
+        const int stride = rm::scene(d->scene_id)->entry_bytes(d->strategy_id);
+        int rc;
+        for (int q = 0; q < (park[1] > 0 ? 2 : 1); ++q) {
+            if ((rc = g.queue[q].ensure((size_t)cap * (size_t)stride))) return rc;
+            a.queue[q] = (unsigned char*)g.queue[q].p;
+        }
+        a.queue_cap = (int32_t)cap;
+        a.queue_stride = stride;
+        a.suspend_after = park[0];
+        a.suspend_queue = 0;
+        a.block_var = nullptr;      // parked pixels are missing at flush time: reduced from the finished map below
+    }
     HIP_TRY(rm::scene(d->scene_id)->render(d->strategy_id, tile_h, a, grid, s));
+    if (park[0] > 0) {
+        rm::KernelArgs b = a;
+        b.suspend_after = park[1];
+        b.suspend_queue = 1;
+        b.refill_min = 16;
+        b.resume_waves = (d->reserved & 0xf) ? (d->reserved & 0xf) : 4;
+        const int rgrid = d->resume_grid > 0 ? d->resume_grid : grid;
+        HIP_TRY(rm::scene(d->scene_id)->resume(d->strategy_id, 0, b, rgrid, s));
+        if (park[1] > 0) {
+            b.suspend_after = 0;
+            b.interleave = 0;       // a sparse pass of very long rays is latency-bound: whole evaluations per turn
+            b.resume_waves = ((d->reserved >> 4) & 0xf) ? ((d->reserved >> 4) & 0xf) : 4;
+            HIP_TRY(rm::scene(d->scene_id)->resume(d->strategy_id, 1, b, rgrid, s));
+        }
+        if (block_var) {
+            const long long nb = (long long)(a.width >> 3) * (a.rows >> 2) * a.nframes;
+            if (nb > 0) {
+                hipLaunchKernelGGL(block_var_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, a.iters, a.width,
+                                   a.rows, a.nframes, block_var);
+                HIP_TRY(hipGetLastError());
+            }
+        }
+    }
     return RM_OK;
 }
 
@@ -261,7 +341,7 @@ void decode_stats(const unsigned long long* w, RmStats* out)
     out->iter_max = (int32_t)w[3];
     out->total_rays = w[5];
     out->iter_min = w[5] ? (int32_t)(0x7fffffffull - w[4]) : 0;
-    for (int b = 0; b < RM_HIST_BINS; ++b) out->iter_hist[b] = w[8 + b];
+    for (int b = 0; b < RM_HIST_BINS; ++b) out->iter_hist[b] = w[rm::kStatsHead + b];
 }
 
 void summarise(RmTiming* t)
@@ -372,7 +452,7 @@ void rm_shutdown(void)
     (void)hipSetDevice(g.device);
     (void)hipStreamSynchronize(g.stream);
     for (Buf* b : { &g.bstats, &g.stats, &g.depth, &g.iters, &g.hit, &g.traw, &g.fs, &g.bvar, &g.in0, &g.in1, &g.out0, &g.out1,
-                    &g.out2, &g.out3, &g.tcost, &g.torder })
+                    &g.out2, &g.out3, &g.tcost, &g.torder, &g.queue[0], &g.queue[1] })
         b->release();
     if (g.events) for (auto& e : g.ev) (void)hipEventDestroy(e);
     g.events = false;

@@ -42,11 +42,14 @@ namespace rm {
 
 constexpr int kTileW = 64;          // one tile row == one wavefront-wide store
 constexpr int kHistBins = 544;      // iterations <= max_iterations + 9 (Segment 521, RevAA 520) for 512
-constexpr int kStatsWords = 8 + kHistBins;  // u64 words, layout below
+constexpr int kStatsHead = 16;
+constexpr int kStatsWords = kStatsHead + kHistBins;  // u64 words, layout below
+constexpr int kQueues = 2;          // suspended-ray queues (ping-pong between resume levels)
 
 // device-side stats block (u64 words):
 //  [0] tile counter   [1] hit_count   [2] sum_iters   [3] iter_max   [4] 0x7fffffff - iter_min
-//  [5] rays written   [6..7] reserved [8 .. 8+kHistBins) histogram of iterations
+//  [5] rays written   [6..7] entries pushed to suspended-ray queue 0 / 1   [8..9] entries handed out
+//  of queue 0 / 1   [10..15] reserved   [16 .. 16+kHistBins) histogram of iterations
 // One frame of a launch: its camera and march configuration.  A launch renders `nframes` frames of the
 // same shape (1 for rm_render; rm_render_batch renders a whole viewpoint / budget sweep in one launch);
 // tile ids run frame-major, the output arrays are frame-major too.
@@ -74,6 +77,12 @@ struct KernelArgs {
     double* final_sdf;        // optional: MarchResult.final_sdf (needs cfg.full)
     long long* block_var;     // optional: (rows/4) x (width/8) variance numerators 32*sum(x^2)-sum(x)^2
     unsigned long long* stats;
+    // Long-ray suspension (see resume_kernel): a ray still marching when its loop index reaches
+    // `suspend_after` is parked in queue `suspend_queue` (state = the strategy record) and its lane
+    // takes a fresh pixel; 0 = never.  Queues hold `queue_cap` entries of `queue_stride` bytes.
+    int32_t suspend_after, suspend_queue, queue_cap, queue_stride;
+    int32_t resume_waves;        // resume_kernel: waves of a workgroup that take rays (1..4)
+    unsigned char* queue[kQueues];
     const int32_t* tile_order;  // optional: permutation of the tile ids (longest-first schedule)
     int32_t* tile_cost;         // optional: per tile, the largest iteration count of its rays
 };
@@ -86,13 +95,10 @@ __device__ __forceinline__ int rank_in_mask(unsigned long long m)
 
 // t_raw / final_sdf are parity-test outputs (fp64, every ray): written straight to global
 // memory when requested, never staged (they are not part of the 9 B/ray product path).
-__device__ __forceinline__ void store_raw(const KernelArgs& a, size_t out0, int x0, int y0, int pix, const Result& r)
+__device__ __forceinline__ void store_raw(const KernelArgs& a, uint32_t gi, const Result& r)
 {
-    if (a.t_raw || a.final_sdf) {
-        const size_t gi = out0 + (size_t)(y0 + (pix >> 6)) * (size_t)a.width + (size_t)(x0 + (pix & 63));
-        if (a.t_raw) a.t_raw[gi] = r.t;
-        if (a.final_sdf) a.final_sdf[gi] = r.final_sdf;
-    }
+    if (a.t_raw) a.t_raw[gi] = r.t;
+    if (a.final_sdf) a.final_sdf[gi] = r.final_sdf;
 }
 
 constexpr int kWavesPerWG = 4;         // 256-thread workgroups: four waves share one LDS copy of the libm tables
@@ -135,6 +141,65 @@ __device__ __forceinline__ void wave_lds_fence()
 }
 
 constexpr int kSlots = 3;   // tiles a wave may have in flight: one being handed out + two draining
+constexpr uint32_t kSuspended = 0xffffffffu;   // staging mark of a pixel whose ray was parked (resume_kernel writes it)
+
+// A parked ray: where its result goes (element index in the frame-major output arrays) and the
+// strategy record, which is the whole march state between two SDF evaluations.
+template <class Strat>
+struct QEntry {
+    uint32_t gi;
+    uint32_t pad;
+    Strat s;
+};
+
+// Wave-uniform call: lanes with `want` append their ray to queue q (one atomic per wave).  Returns
+// per lane whether the ray was parked; a full queue leaves the ray where it is.
+template <class Strat>
+__device__ __forceinline__ bool push_suspended(const KernelArgs& a, int q, bool want, uint32_t gi, const Strat& s)
+{
+    const unsigned long long m = __ballot(want);
+    if (m == 0) return false;
+    unsigned int base = 0;
+    if (lane_id() == 0) base = (unsigned int)atomicAdd(&a.stats[6 + q], (unsigned long long)__popcll(m));
+    base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+    const unsigned int idx = base + (unsigned int)rank_in_mask(m);
+    const bool ok = want && idx < (unsigned int)a.queue_cap;
+    if (ok) {
+        QEntry<Strat>* e = (QEntry<Strat>*)a.queue[q] + idx;
+        e->gi = gi;
+        e->pad = 0;
+        e->s = s;
+    }
+    return ok;
+}
+
+// Per-wave frame totals kept in registers; one atomic each at kernel exit.
+struct WaveAcc {
+    unsigned long long hits = 0, iters = 0, rays = 0;
+    int mx = 0, mn = 0x7fffffff;
+    __device__ __forceinline__ void add(int it, int h)
+    {
+        hits += (unsigned)h; iters += (unsigned)it; rays += 1;
+        mx = max(mx, it); mn = min(mn, it);
+    }
+    __device__ __forceinline__ void flush(unsigned long long* stats)
+    {
+        for (int off = 32; off > 0; off >>= 1) {
+            hits += __shfl_xor(hits, off);
+            iters += __shfl_xor(iters, off);
+            rays += __shfl_xor(rays, off);
+            mx = max(mx, __shfl_xor(mx, off));
+            mn = min(mn, __shfl_xor(mn, off));
+        }
+        if (lane_id() == 0 && rays) {
+            atomicAdd(&stats[1], hits);
+            atomicAdd(&stats[2], iters);
+            atomicMax(&stats[3], (unsigned long long)mx);
+            atomicMax(&stats[4], (unsigned long long)(0x7fffffff - mn));   // zero-initialised => store the complement
+            atomicAdd(&stats[5], rays);
+        }
+    }
+};
 
 // Tile geometry (wave-uniform): frame, origin inside the frame slice, valid extent, image row of its
 // first row, element offset of the frame in the frame-major output arrays.
@@ -190,9 +255,7 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
     rm_load_tables<Scene>();
     __syncthreads();
 
-    unsigned long long acc_hits = 0, acc_iters = 0, acc_rays = 0;
-    int acc_max = 0, acc_min = 0x7fffffff;
-
+    WaveAcc acc;
 
     // wave-uniform scheduler state: the tiles in flight
     int slot_tile[kSlots], slot_out[kSlots];      // tile id (-1 = free) and rays handed out but not finished
@@ -206,6 +269,7 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
     // per-lane state: the ray this lane carries
     bool active = false;
     int my_slot = 0, my_pix = 0;                  // where its result goes: slot, tile-linear index y*64+x
+    uint32_t my_gi = 0;                           // ... and its element index in the output arrays
     vec3 origin = v3(0.0, 0.0, 0.0), dir = v3(0.0, 0.0, 0.0);
     MarchCfg cfg;                                 // of the frame this lane's ray belongs to
     cfg.hit_threshold = 0.0; cfg.max_distance = 0.0; cfg.lipschitz = 1.0; cfg.max_iterations = 0; cfg.full = a.full;
@@ -236,19 +300,17 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
                         const int li = r * kTileW + lane;
                         const size_t gi = g.out0 + (size_t)(g.y0 + r) * (size_t)a.width + (size_t)gx;
                         const uint32_t ih = s_ih[k][li];
-                        const int it = (int)(ih & 0x7fffffffu);
-                        const int h = (int)(ih >> 31);
-                        a.depth[gi] = s_depth[k][li];
-                        a.iters[gi] = it;
-                        a.hit[gi] = (uint8_t)h;
-                        acc_hits += (unsigned)h;
-                        acc_iters += (unsigned)it;
-                        acc_rays += 1;
-                        acc_max = max(acc_max, it);
-                        acc_min = min(acc_min, it);
-                        atomicAdd(&s_hist[min(it, a.hist_bins - 1)], 1u);
-                        bs += it;
-                        bq += (long long)it * it;
+                        if (ih != kSuspended) {     // a parked ray's pixel is written by resume_kernel
+                            const int it = (int)(ih & 0x7fffffffu);
+                            const int h = (int)(ih >> 31);
+                            a.depth[gi] = s_depth[k][li];
+                            a.iters[gi] = it;
+                            a.hit[gi] = (uint8_t)h;
+                            acc.add(it, h);
+                            atomicAdd(&s_hist[min(it, a.hist_bins - 1)], 1u);
+                            bs += it;
+                            bq += (long long)it * it;
+                        }
                     }
                     if ((r & 3) == 3) {
                         // reduce the 8 columns of each 8x4 block (lanes 8k..8k+7)
@@ -269,7 +331,10 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
                     int tmax = 0;
 #pragma unroll
                     for (int r = 0; r < TILE_H; ++r)
-                        if (r < g.th && col_ok) tmax = max(tmax, (int)(s_ih[k][r * kTileW + lane] & 0x7fffffffu));
+                        if (r < g.th && col_ok) {
+                            const uint32_t ih = s_ih[k][r * kTileW + lane];
+                            tmax = max(tmax, ih == kSuspended ? a.suspend_after : (int)(ih & 0x7fffffffu));
+                        }
                     for (int off = 32; off > 0; off >>= 1) tmax = max(tmax, __shfl_xor(tmax, off));
                     if (lane == 0) a.tile_cost[slot_tile[k]] = tmax;
                 }
@@ -319,6 +384,7 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
                     if (id < TILE_PIX && px < cg.tw && py < cg.th) {
                         my_slot = cur;
                         my_pix = py * kTileW + px;
+                        my_gi = (uint32_t)(cg.out0 + (size_t)(cg.y0 + py) * (size_t)a.width + (size_t)(cg.x0 + px));
                         FrameParams fp;                                   // wave-uniform: scalar loads either way
                         if (a.frames) fp = a.frames[cg.frame]; else fp = a.single;
                         camera_ray(fp.cam, a.width, a.height, cg.x0 + px, cg.gy0 + py, origin, dir);
@@ -329,7 +395,7 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
                         if (s.start(cfg)) {
                             s_depth[cur][my_pix] = s.res.hit ? (float)s.res.t : 0.0f;
                             s_ih[cur][my_pix] = (uint32_t)s.res.iters | ((uint32_t)s.res.hit << 31);
-                            store_raw(a, cg.out0, cg.x0, cg.y0, my_pix, s.res);
+                            store_raw(a, my_gi, s.res);
                         } else {
                             active = true;
                             started = true;
@@ -359,7 +425,7 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
         }
 
         // ---- 4. one SDF evaluation (INTERLEAVE: one trip of it) for every live ray -----------------
-        bool fin = false;
+        bool fin = false, park = false;
         bool consume = active;
         if constexpr (INTERLEAVE) consume = active && ready;
         if (!INTERLEAVE || __any(consume)) {
@@ -372,15 +438,22 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
                 fin = true;
                 s_depth[my_slot][my_pix] = s.res.hit ? (float)s.res.t : 0.0f;   // types.py:93
                 s_ih[my_slot][my_pix] = (uint32_t)s.res.iters | ((uint32_t)s.res.hit << 31);
-                if (a.t_raw || a.final_sdf) {   // parity-test outputs: straight to global memory
-                    int t_of_slot = 0;
-#pragma unroll
-                    for (int k = 0; k < kSlots; ++k) t_of_slot = (k == my_slot) ? slot_tile[k] : t_of_slot;
-                    const TileGeom gs = tile_geom<TILE_H>(a, t_of_slot);
-                    store_raw(a, gs.out0, gs.x0, gs.y0, my_pix, s.res);
-                }
+                store_raw(a, my_gi, s.res);
+            } else if (a.suspend_after > 0 && s.i >= a.suspend_after) {
+                park = true;
             } else if constexpr (INTERLEAVE) {
                 ready = Scene::begin(ev, origin + dir * s.te);   // ray.py:15-17
+            }
+        }
+        if (a.suspend_after > 0 && __any(park)) {
+            // long rays leave the wave: their lanes take fresh pixels, resume_kernel finishes them
+            const bool parked = push_suspended(a, a.suspend_queue, park, my_gi, s);
+            if (parked) {
+                s_ih[my_slot][my_pix] = kSuspended;
+                active = false;
+                fin = true;
+            } else if (park) {
+                if constexpr (INTERLEAVE) ready = Scene::begin(ev, origin + dir * s.te);   // queue full: march on
             }
         }
         if (__any(fin)) {
@@ -395,24 +468,145 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
     }
 
     // ---- per-wave totals -> one atomic each; histogram flush -----------------------
-    for (int off = 32; off > 0; off >>= 1) {
-        acc_hits += __shfl_xor(acc_hits, off);
-        acc_iters += __shfl_xor(acc_iters, off);
-        acc_rays += __shfl_xor(acc_rays, off);
-        acc_max = max(acc_max, __shfl_xor(acc_max, off));
-        acc_min = min(acc_min, __shfl_xor(acc_min, off));
-    }
-    if (lane == 0 && acc_rays) {
-        atomicAdd(&a.stats[1], acc_hits);
-        atomicAdd(&a.stats[2], acc_iters);
-        atomicMax(&a.stats[3], (unsigned long long)acc_max);
-        atomicMax(&a.stats[4], (unsigned long long)(0x7fffffff - acc_min));   // zero-initialised => store the complement
-        atomicAdd(&a.stats[5], acc_rays);
-    }
+    acc.flush(a.stats);
     __syncthreads();   // every wave of the workgroup has left its loop
     for (int b = threadIdx.x; b < kHistBins; b += blockDim.x) {
         const unsigned int c = s_hist[b];
-        if (c) atomicAdd(&a.stats[8 + b], (unsigned long long)c);
+        if (c) atomicAdd(&a.stats[kStatsHead + b], (unsigned long long)c);
+    }
+}
+
+// ---- long-ray resume ------------------------------------------------------------------------
+//
+// A frame's time is bounded below by its longest ray, and a long ray only starts when the tile
+// order reaches its pixel.  render_kernel therefore parks every ray that is still marching after
+// `suspend_after` loop trips (a few per cent of the frame) and moves on, so the first pass is over
+// quickly; this kernel then restarts all parked rays AT ONCE -- dense wavefronts of long rays, every
+// one of them running from the first microsecond of the pass -- and may park the longest of them
+// again for a last, sparse pass.  The march state between two SDF evaluations is the strategy
+// record, so a resumed ray continues bit-for-bit where it stopped.  Results go straight to the
+// output arrays (scattered 4 + 4 + 1 byte stores of a few per cent of the pixels).
+template <class Scene, class Strat, bool INTERLEAVE>
+__global__ __launch_bounds__(64 * kWavesPerWG) void resume_kernel(const KernelArgs a, const int level)
+{
+    static_assert(!INTERLEAVE || SceneIterative<Scene>::value, "INTERLEAVE needs Scene::Eval");
+    using Entry = QEntry<Strat>;
+    __shared__ unsigned int s_hist[kHistBins];
+    const int lane = lane_id();
+    for (int b = threadIdx.x; b < kHistBins; b += blockDim.x) s_hist[b] = 0u;
+    rm_load_tables<Scene>();
+    __syncthreads();
+
+    const unsigned long long pushed = a.stats[6 + level];          // final: the producer kernel has completed
+    const unsigned int count = (unsigned int)min(pushed, (unsigned long long)a.queue_cap);
+    const Entry* const queue = (const Entry*)a.queue[level];
+    const uint32_t frame_elems = (uint32_t)a.rows * (uint32_t)a.width;
+
+    WaveAcc acc;
+    // wave-uniform: the queue may still hold entries for this wave.  Only the first `resume_waves` waves
+    // of a workgroup take rays (measured: a pass of few, very long rays runs fastest packed into few
+    // wavefronts on few compute units -- the rest of the device idles and the busy part clocks higher).
+    bool more = count > 0 && (int)(threadIdx.x >> 6) < a.resume_waves;
+    bool active = false;
+    uint32_t my_gi = 0;
+    vec3 origin = v3(0.0, 0.0, 0.0), dir = v3(0.0, 0.0, 0.0);
+    MarchCfg cfg;
+    cfg.hit_threshold = 0.0; cfg.max_distance = 0.0; cfg.lipschitz = 1.0; cfg.max_iterations = 0; cfg.full = a.full;
+    Strat s;
+    typename EvalOf<Scene, INTERLEAVE>::type ev;
+    bool ready = false;
+
+    for (;;) {
+        // ---- refill idle lanes from the queue ----------------------------------------------------
+        const unsigned long long idle = __ballot(!active);
+        const int nidle = __popcll(idle);
+        if (more && (nidle >= a.refill_min || nidle == 64)) {
+            const int take = nidle;
+            unsigned int base = 0;
+            if (lane == 0) base = (unsigned int)atomicAdd(&a.stats[8 + level], (unsigned long long)take);
+            base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+            if (base >= count) {
+                more = false;                     // every wave gets here: the grid always drains
+            } else if (!active) {
+                const int rank = rank_in_mask(idle);
+                const unsigned int idx = base + (unsigned int)rank;
+                if (rank < take && idx < count) {
+                    const Entry e = queue[idx];
+                    my_gi = e.gi;
+                    s = e.s;
+                    const uint32_t frame = my_gi / frame_elems;
+                    const uint32_t pix = my_gi - frame * frame_elems;
+                    const int y = (int)(pix / (uint32_t)a.width);
+                    const int x = (int)(pix - (uint32_t)y * (uint32_t)a.width);
+                    const int gy = a.band_rows > 0
+                        ? a.row0 + ((y / a.band_rows) * a.band_stride + a.band_offset) * a.band_rows + (y % a.band_rows)
+                        : a.row0 + y;
+                    FrameParams fp;
+                    if (a.frames) fp = a.frames[frame]; else fp = a.single;
+                    camera_ray(fp.cam, a.width, a.height, x, gy, origin, dir);   // recomputed: same bits as the first pass
+                    cfg.hit_threshold = fp.cfg.hit_threshold;
+                    cfg.max_distance = fp.cfg.max_distance;
+                    cfg.lipschitz = fp.cfg.lipschitz;
+                    cfg.max_iterations = fp.cfg.max_iterations;
+                    active = true;
+                    if constexpr (INTERLEAVE) ready = Scene::begin(ev, origin + dir * s.te);
+                }
+            }
+        }
+        if (!__any(active)) {
+            if (!more) break;                     // wave-uniform
+            continue;                             // the next turn refills (nidle == 64) or ends the queue
+        }
+
+        // ---- one SDF evaluation (INTERLEAVE: one trip of it) for every live ray ---------------------
+        bool park = false;
+        bool consume = active;
+        if constexpr (INTERLEAVE) consume = active && ready;
+        if (!INTERLEAVE || __any(consume)) {
+            if (consume) {
+                double d;
+                if constexpr (INTERLEAVE) d = Scene::value(ev);
+                else d = Scene::sdf(origin + dir * s.te);   // ray.py:15-17
+                if (s.step(d, cfg)) {
+                    active = false;
+                    const int it = s.res.iters, h = s.res.hit;
+                    a.depth[my_gi] = h ? (float)s.res.t : 0.0f;   // types.py:93
+                    a.iters[my_gi] = it;
+                    a.hit[my_gi] = (uint8_t)h;
+                    store_raw(a, my_gi, s.res);
+                    acc.add(it, h);
+                    atomicAdd(&s_hist[min(it, a.hist_bins - 1)], 1u);
+                    if (a.tile_cost) {
+                        const uint32_t frame = my_gi / frame_elems;
+                        const uint32_t pix = my_gi - frame * frame_elems;
+                        const uint32_t y = pix / (uint32_t)a.width, x = pix - y * (uint32_t)a.width;
+                        atomicMax(&a.tile_cost[frame * (uint32_t)a.tiles_per_frame + (y / 4u) * (uint32_t)a.tiles_x + (x >> 6)], it);
+                    }
+                } else if (a.suspend_after > 0 && s.i >= a.suspend_after) {
+                    park = true;
+                } else if constexpr (INTERLEAVE) {
+                    ready = Scene::begin(ev, origin + dir * s.te);
+                }
+            }
+            if (a.suspend_after > 0 && __any(park)) {
+                const bool parked = push_suspended(a, a.suspend_queue, park, my_gi, s);
+                if (parked) {
+                    active = false;
+                } else if (park) {
+                    if constexpr (INTERLEAVE) ready = Scene::begin(ev, origin + dir * s.te);
+                }
+            }
+        }
+        if constexpr (INTERLEAVE) {
+            if (active && !ready) ready = Scene::trip(ev);
+        }
+    }
+
+    acc.flush(a.stats);
+    __syncthreads();
+    for (int b = threadIdx.x; b < kHistBins; b += blockDim.x) {
+        const unsigned int c = s_hist[b];
+        if (c) atomicAdd(&a.stats[kStatsHead + b], (unsigned long long)c);
     }
 }
 
@@ -442,6 +636,8 @@ __global__ void march_rays_kernel(MarchCfg cfg, const double* __restrict__ origi
 // Per-scene launch table, filled by rm_scene_tu.hip (one translation unit per scene).
 struct SceneLaunchers {
     hipError_t (*render)(int strategy, int tile_h, const KernelArgs& a, int grid, hipStream_t s);
+    hipError_t (*resume)(int strategy, int level, const KernelArgs& a, int grid, hipStream_t s);
+    int (*entry_bytes)(int strategy);   // sizeof(QEntry<Strat>)
     hipError_t (*occupancy)(int strategy, int tile_h, int interleave, int* blocks_per_cu);
     hipError_t (*sdf_eval)(const double* xyz, size_t n, double* out, hipStream_t s);
     hipError_t (*march_rays)(int strategy, const MarchCfg& cfg, const double* o, const double* d, size_t n,

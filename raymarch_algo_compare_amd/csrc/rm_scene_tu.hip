@@ -27,6 +27,16 @@ static hipError_t launch_render(const KernelArgs& a, int grid, hipStream_t s)
     return hipGetLastError();
 }
 
+template <class Strat>
+static hipError_t launch_resume(int level, const KernelArgs& a, int grid, hipStream_t s)
+{
+    if (kIter && a.interleave)
+        hipLaunchKernelGGL((resume_kernel<SceneT, Strat, kIter>), dim3(grid), dim3(64 * kWavesPerWG), 0, s, a, level);
+    else
+        hipLaunchKernelGGL((resume_kernel<SceneT, Strat, false>), dim3(grid), dim3(64 * kWavesPerWG), 0, s, a, level);
+    return hipGetLastError();
+}
+
 template <class Strat, int TH>
 static hipError_t occ_render(int interleave, int* blocks)
 {
@@ -44,6 +54,28 @@ static hipError_t render(int strategy, int tile_h, const KernelArgs& a, int grid
 #undef RM_X
     }
     return hipErrorInvalidValue;
+}
+
+static hipError_t resume(int strategy, int level, const KernelArgs& a, int grid, hipStream_t s)
+{
+    switch (strategy) {
+#define RM_X(id, S) \
+    case id: return launch_resume<S>(level, a, grid, s);
+        RM_STRATEGY_LIST(RM_X)
+#undef RM_X
+    }
+    return hipErrorInvalidValue;
+}
+
+static int entry_bytes(int strategy)
+{
+    switch (strategy) {
+#define RM_X(id, S) \
+    case id: return (int)sizeof(QEntry<S>);
+        RM_STRATEGY_LIST(RM_X)
+#undef RM_X
+    }
+    return 0;
 }
 
 static hipError_t occupancy(int strategy, int tile_h, int interleave, int* blocks)
@@ -85,7 +117,7 @@ static hipError_t march_rays(int strategy, const MarchCfg& cfg, const double* o,
 // a host function (not a const global: hipcc would try to emit that for the device too)
 const SceneLaunchers* RM_CAT(scene_launchers_, RM_SCENE_ID)()
 {
-    static const SceneLaunchers l = { render, occupancy, sdf_eval, march_rays };
+    static const SceneLaunchers l = { render, resume, entry_bytes, occupancy, sdf_eval, march_rays };
     return &l;
 }
 

@@ -46,6 +46,43 @@ elif exp == "interleave":
     for rmn in (1, 4, 16, 32):
         run(10, 0, repeats=5, warmup=2, eval_mode=2, refill_min=rmn)
         run(10, 0, W=3840, H=2160, repeats=3, warmup=1, eval_mode=2, refill_min=rmn)
+elif exp == "suspend":
+    import numpy as np
+    # correctness: parked / resumed rays reproduce the unsuspended frame bit for bit
+    for sid, kid, W, H in ((10, 0, 640, 360), (10, 5, 320, 200), (10, 9, 320, 200), (10, 10, 320, 200), (12, 0, 640, 360),
+                           (13, 3, 333, 121), (9, 6, 640, 360), (0, 8, 640, 360)):
+        scene = registry.SCENES[sid]
+        outs = []
+        for sa in ((-1, -1), (8, 0), (8, 40), (32, 128)):
+            for em in ((1, 2) if sid == 10 else (1,)):
+                desc = _native.make_desc(sid, kid, cam_for(scene, W, H).params14(), W, H, full=True, suspend_after=sa, eval_mode=em)
+                o = _native.render(desc, want_t_raw=True, want_final_sdf=True, want_block_var=(H % 4 == 0 and W % 8 == 0))
+                outs.append(o)
+        ref = outs[0]
+        ok = True
+        for o in outs[1:]:
+            for key in ("depth", "iters", "hit", "t_raw", "final_sdf", "block_var"):
+                if ref[key] is not None and not np.array_equal(ref[key].view(np.uint8), o[key].view(np.uint8)):
+                    ok = False; print("MISMATCH", sid, kid, key, int((ref[key] != o[key]).sum()))
+            for key in ("total_rays", "hit_count", "sum_iters", "iter_max", "iter_min"):
+                if ref["stats"][key] != o["stats"][key]:
+                    ok = False; print("STATS MISMATCH", sid, kid, key, ref["stats"][key], o["stats"][key])
+            if not np.array_equal(ref["stats"]["iter_hist"], o["stats"]["iter_hist"]):
+                ok = False; print("HIST MISMATCH", sid, kid)
+        print("suspend parity", scene.name, registry.list_strategies()[kid], "OK" if ok else "FAILED", flush=True)
+    for sa in ((-1, -1), (16, 0), (32, 0), (48, 0), (64, 0), (16, 64), (32, 96), (32, 128), (48, 128), (24, 64), (32, 192)):
+        for em in (1, 2):
+            run(10, 0, repeats=7, warmup=2, eval_mode=em, suspend_after=sa)
+    for sa in ((-1, -1), (32, 128)):
+        for sid, kid in ((10, 4), (10, 6), (10, 10), (12, 0), (13, 0), (0, 0), (9, 0)):
+            run(sid, kid, repeats=5, warmup=2, suspend_after=sa)
+        run(10, 0, W=3840, H=2160, repeats=3, warmup=1, suspend_after=sa)
+        run(10, 0, W=7680, H=4320, repeats=3, warmup=1, suspend_after=sa)
+elif exp == "spread":
+    # reserved = resume_waves of level 0 | level 1 << 4
+    for sa in ((32, 128), (32, 96), (48, 128), (32, 192)):
+        for rw in (0x44, 0x14, 0x24, 0x12, 0x22, 0x11):
+            run(10, 0, repeats=7, warmup=2, eval_mode=2, suspend_after=sa, reserved=rw)
 elif exp == "one":
     run(int(sys.argv[2]), int(sys.argv[3]), repeats=int(sys.argv[4]) if len(sys.argv) > 4 else 5)
 elif exp == "matrix":
