@@ -85,8 +85,11 @@ typedef struct RmFrameDesc {
      * trips for a last sparse pass.  A parked ray continues from its saved strategy state, so results
      * are identical with or without suspension.  Per entry: 0 = library default, < 0 = off. */
     int32_t suspend_after[2];
-    int32_t resume_grid;   /* 0 = default; workgroups of the resume passes (developer knob) */
-    int32_t reserved;
+    int32_t resume_grid;   /* 0 = default (one per compute unit); workgroups of the resume passes */
+    /* How parked rays are finished.  0 = default (2 where the scene has a team form), 1 = one wavefront per
+     * 64 rays, 2 = wavefront TEAMS for the last pass: three waves carry the same 64 rays and each evaluates
+     * one of the three independent transcendental chains of a Mandelbulb trip (rm_march_rays_team). */
+    int32_t resume_mode;
 } RmFrameDesc;
 
 /* Frame reduce computed in-kernel (the integer part of RayMarchStats.compute, core/types.py:77-137). */
@@ -135,6 +138,12 @@ int rm_sdf_eval(int scene_id, const double* xyz, size_t n, double* out);
  * Directions are normalised as Ray.__init__ does (core/ray.py:11-13). */
 int rm_march_rays(int scene_id, int strategy_id, const RmMarchConfig* cfg, const double* origins,
                   const double* dirs, size_t n, uint8_t* hit, double* t, int32_t* iters, double* final_sdf);
+
+/* Same contract, evaluated by wavefront TEAMS (scenes whose SDF is a loop of independent
+ * transcendental chains -- Mandelbulb: three waves carry the same 64 rays and each evaluates one
+ * chain per trip; see rm_kernels.h).  Identical results; RM_E_BAD_SCENE for scenes without a team form. */
+int rm_march_rays_team(int scene_id, int strategy_id, const RmMarchConfig* cfg, const double* origins,
+                       const double* dirs, size_t n, uint8_t* hit, double* t, int32_t* iters, double* final_sdf);
 
 /* MetricsCollector.benchmark_strategy (metrics/collector.py:19-66): render the frame and
  * copy the maps back.  Host pointers; depth/iters/hit are required (depth is fp32: t if hit

@@ -23,7 +23,7 @@ ERROR_NAMES = {0: "RM_OK", -1: "RM_E_BAD_SCENE", -2: "RM_E_BAD_STRATEGY", -3: "R
 
 EXPORTS = [
     "rm_init", "rm_shutdown", "rm_last_error", "rm_device_info", "rm_num_scenes", "rm_num_strategies",
-    "rm_sdf_eval", "rm_march_rays", "rm_render", "rm_render_device", "rm_stats_device_bytes",
+    "rm_sdf_eval", "rm_march_rays", "rm_march_rays_team", "rm_render", "rm_render_device", "rm_stats_device_bytes",
     "rm_read_stats", "rm_bench_device", "rm_alloc_frame", "rm_free_frame", "rm_copy_frame_to_host",
     "rm_bench_store_path", "rm_render_batch",
 ]
@@ -51,7 +51,7 @@ class RmFrameDesc(ctypes.Structure):
                 ("band_stride", ctypes.c_int32), ("band_offset", ctypes.c_int32),
                 ("tile_order_mode", ctypes.c_int32), ("eval_mode", ctypes.c_int32),
                 ("suspend_after", ctypes.c_int32 * 2),
-                ("resume_grid", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("resume_grid", ctypes.c_int32), ("resume_mode", ctypes.c_int32)]
 
 
 class RmStats(ctypes.Structure):
@@ -97,6 +97,7 @@ def load() -> ctypes.CDLL:
         L.rm_sdf_eval.argtypes = [ctypes.c_int, dp, ctypes.c_size_t, dp]
         L.rm_march_rays.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(RmMarchConfig), dp, dp,
                                     ctypes.c_size_t, vp, dp, vp, dp]
+        L.rm_march_rays_team.argtypes = L.rm_march_rays.argtypes
         L.rm_render.argtypes = [ctypes.POINTER(RmFrameDesc), vp, vp, vp, vp, vp, vp,
                                 ctypes.POINTER(RmStats), ctypes.POINTER(RmTiming)]
         L.rm_render_device.argtypes = [ctypes.POINTER(RmFrameDesc), vp, vp, vp, vp, vp]
@@ -151,7 +152,7 @@ def device_info() -> dict:
 def make_desc(scene_id, strategy_id, cam14, width, height, row0=0, rows=None, max_iterations=512,
               hit_threshold=1e-4, max_distance=100.0, lipschitz=1.0, full=False, tile_rows=0, refill_min=0,
               grid_waves=0, band_rows=0, band_stride=0, band_offset=0, tile_order_mode=0, eval_mode=0,
-              suspend_after=(0, 0), resume_grid=0, reserved=0) -> RmFrameDesc:
+              suspend_after=(0, 0), resume_grid=0, resume_mode=0) -> RmFrameDesc:
     d = RmFrameDesc()
     d.scene_id, d.strategy_id = int(scene_id), int(strategy_id)
     d.width, d.height = int(width), int(height)
@@ -173,7 +174,7 @@ def make_desc(scene_id, strategy_id, cam14, width, height, row0=0, rows=None, ma
     d.eval_mode = int(eval_mode)
     d.suspend_after[0], d.suspend_after[1] = int(suspend_after[0]), int(suspend_after[1])
     d.resume_grid = int(resume_grid)
-    d.reserved = int(reserved)
+    d.resume_mode = int(resume_mode)
     return d
 
 
@@ -260,7 +261,7 @@ def sdf_eval(scene_id: int, pts) -> np.ndarray:
 
 
 def march_rays(scene_id, strategy_id, origins, dirs, max_iterations=512, hit_threshold=1e-4, max_distance=100.0,
-               lipschitz=1.0):
+               lipschitz=1.0, team=False):
     L = init()
     origins = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
     dirs = np.ascontiguousarray(dirs, dtype=np.float64).reshape(-1, 3)
@@ -269,7 +270,7 @@ def march_rays(scene_id, strategy_id, origins, dirs, max_iterations=512, hit_thr
     hit, t = np.empty(n, np.uint8), np.empty(n, np.float64)
     iters, fs = np.empty(n, np.int32), np.empty(n, np.float64)
     dp = ctypes.POINTER(ctypes.c_double)
-    check(L.rm_march_rays(int(scene_id), int(strategy_id), ctypes.byref(cfg), origins.ctypes.data_as(dp),
-                          dirs.ctypes.data_as(dp), n, _ptr(hit), t.ctypes.data_as(dp), _ptr(iters),
-                          fs.ctypes.data_as(dp)))
+    fn = L.rm_march_rays_team if team else L.rm_march_rays
+    check(fn(int(scene_id), int(strategy_id), ctypes.byref(cfg), origins.ctypes.data_as(dp),
+             dirs.ctypes.data_as(dp), n, _ptr(hit), t.ctypes.data_as(dp), _ptr(iters), fs.ctypes.data_as(dp)))
     return hit, t, iters, fs

@@ -81,7 +81,6 @@ struct KernelArgs {
     // `suspend_after` is parked in queue `suspend_queue` (state = the strategy record) and its lane
     // takes a fresh pixel; 0 = never.  Queues hold `queue_cap` entries of `queue_stride` bytes.
     int32_t suspend_after, suspend_queue, queue_cap, queue_stride;
-    int32_t resume_waves;        // resume_kernel: waves of a workgroup that take rays (1..4)
     unsigned char* queue[kQueues];
     const int32_t* tile_order;  // optional: permutation of the tile ids (longest-first schedule)
     int32_t* tile_cost;         // optional: per tile, the largest iteration count of its rays
@@ -503,10 +502,10 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void resume_kernel(const KernelAr
     const uint32_t frame_elems = (uint32_t)a.rows * (uint32_t)a.width;
 
     WaveAcc acc;
-    // wave-uniform: the queue may still hold entries for this wave.  Only the first `resume_waves` waves
-    // of a workgroup take rays (measured: a pass of few, very long rays runs fastest packed into few
-    // wavefronts on few compute units -- the rest of the device idles and the busy part clocks higher).
-    bool more = count > 0 && (int)(threadIdx.x >> 6) < a.resume_waves;
+    // wave-uniform: the queue may still hold entries.  Waves take 64 rays at a time: measured, a pass of
+    // few very long rays runs fastest packed into few wavefronts (dealing them out thinly over every
+    // SIMD was 1.5x slower -- the whole device busy with one chain per SIMD clocks lower).
+    bool more = count > 0;
     bool active = false;
     uint32_t my_gi = 0;
     vec3 origin = v3(0.0, 0.0, 0.0), dir = v3(0.0, 0.0, 0.0);
@@ -633,15 +632,196 @@ __global__ void march_rays_kernel(MarchCfg cfg, const double* __restrict__ origi
     hit[i] = (uint8_t)r.hit; t[i] = r.t; iters[i] = r.iters; final_sdf[i] = r.final_sdf;
 }
 
+// ---- wavefront teams ------------------------------------------------------------------------
+//
+// The time of a frame is bounded below by its longest ray, and a ray is one dependent chain of
+// instructions: more lanes do not shorten it.  More WAVEFRONTS do: the three transcendental chains
+// of a Mandelbulb trip (Scene::trip_part 0..2) are independent, so a team of kTeam wavefronts -- one
+// per SIMD of a compute unit -- carries the same 64 rays, every wave evaluates ONE of the chains for
+// all 64 rays and the results are exchanged through LDS (one workgroup barrier per trip).  All waves
+// hold the same ray state and run the same control flow (same data, same decisions), so ballots,
+// loop counts and barriers line up by construction.  The instruction stream of a trip drops from
+// ~1060 to ~360 per wave; the total work stays about the same.
+constexpr int kTeam = 3;
+
+// Exchange buffer of a team: [trip parity][value 0..5][lane]; double-buffered so one barrier per trip
+// suffices (a wave can only overwrite a buffer after every wave has passed the barrier that follows
+// the reads of its previous use).
+struct TeamXch {
+    double v[2][2 * kTeam][64];
+};
+
+// One trip for a team; `turn` counts the team's trips (buffer parity).  Wave-uniform call.
+template <class Scene>
+__device__ __forceinline__ bool team_trip(typename Scene::Eval& ev, bool go, int part, int lane, TeamXch& x, int& turn)
+{
+    double o0 = 0.0, o1 = 0.0;
+    if (go) Scene::trip_part(ev, part, o0, o1);
+    double (*buf)[64] = x.v[turn & 1];
+    ++turn;
+    buf[2 * part][lane] = o0;
+    buf[2 * part + 1][lane] = o1;
+    __syncthreads();
+    bool done = true;
+    if (go) done = Scene::trip_join(ev, buf[0][lane], buf[1][lane], buf[2][lane], buf[3][lane], buf[4][lane], buf[5][lane]);
+    return done;
+}
+
+// rm_march_rays for a team: 64 rays per workgroup of kTeam waves (no lane refill)
+template <class Scene, class Strat>
+__global__ __launch_bounds__(64 * kTeam) void march_rays_team_kernel(MarchCfg cfg, const double* __restrict__ origins,
+                                                                     const double* __restrict__ dirs, size_t n, uint8_t* hit,
+                                                                     double* t, int32_t* iters, double* final_sdf)
+{
+    __shared__ TeamXch xch;
+    rm_load_tables<Scene>();
+    const int lane = lane_id();
+    const int part = (int)(threadIdx.x >> 6);
+    const size_t i = (size_t)blockIdx.x * 64 + (size_t)lane;
+    const bool have = i < n;
+    vec3 o = v3(0.0, 0.0, 0.0), d = v3(0.0, 0.0, 1.0);
+    if (have) {
+        o = v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
+        d = normalized(v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]));   // Ray.__init__ normalises
+    }
+    Strat s;
+    bool done = true;
+    if (have) done = s.start(cfg);
+    typename Scene::Eval ev;
+    int turn = 0;
+    while (__any(!done)) {
+        bool ready = true;
+        if (!done) ready = Scene::begin(ev, o + d * s.te);
+        while (__any(!ready)) {
+            const bool fin = team_trip<Scene>(ev, !ready, part, lane, xch, turn);
+            if (!ready) ready = fin;
+        }
+        if (!done) done = s.step(Scene::value(ev), cfg);
+    }
+    if (have && part == 0) {
+        hit[i] = (uint8_t)s.res.hit; t[i] = s.res.t; iters[i] = s.res.iters; final_sdf[i] = s.res.final_sdf;
+    }
+}
+
+// resume_kernel for teams: one team per workgroup carries 64 parked rays at a time; every wave holds
+// the same state and takes the same decisions, wave 0 owns the side effects (queue pops, stores, stats).
+// Whole evaluations per turn: the rays that reach this pass are long, near-surface rays whose
+// evaluations all take most of the 8 trips.
+template <class Scene, class Strat>
+__global__ __launch_bounds__(64 * kTeam) void resume_team_kernel(const KernelArgs a, const int level)
+{
+    using Entry = QEntry<Strat>;
+    __shared__ TeamXch xch;
+    __shared__ unsigned int s_hist[kHistBins];
+    __shared__ unsigned int s_base;
+    const int lane = lane_id();
+    const int part = (int)(threadIdx.x >> 6);
+    for (int b = threadIdx.x; b < kHistBins; b += blockDim.x) s_hist[b] = 0u;
+    rm_load_tables<Scene>();
+    __syncthreads();
+
+    const unsigned long long pushed = a.stats[6 + level];
+    const unsigned int count = (unsigned int)min(pushed, (unsigned long long)a.queue_cap);
+    const Entry* const queue = (const Entry*)a.queue[level];
+    const uint32_t frame_elems = (uint32_t)a.rows * (uint32_t)a.width;
+
+    WaveAcc acc;
+    bool more = count > 0;
+    bool active = false;
+    uint32_t my_gi = 0;
+    vec3 origin = v3(0.0, 0.0, 0.0), dir = v3(0.0, 0.0, 0.0);
+    MarchCfg cfg;
+    cfg.hit_threshold = 0.0; cfg.max_distance = 0.0; cfg.lipschitz = 1.0; cfg.max_iterations = 0; cfg.full = a.full;
+    Strat s;
+    typename Scene::Eval ev;
+    int turn = 0;
+
+    for (;;) {
+        const unsigned long long idle = __ballot(!active);
+        const int nidle = __popcll(idle);
+        if (more && (nidle >= a.refill_min || nidle == 64)) {      // same decision in every wave of the team
+            if (part == 0 && lane == 0) s_base = (unsigned int)atomicAdd(&a.stats[8 + level], (unsigned long long)nidle);
+            __syncthreads();
+            const unsigned int base = (unsigned int)__builtin_amdgcn_readfirstlane((int)s_base);
+            __syncthreads();                      // s_base may be rewritten on the next turn
+            if (base >= count) {
+                more = false;
+            } else if (!active) {
+                const unsigned int idx = base + (unsigned int)rank_in_mask(idle);
+                if (idx < count) {
+                    const Entry e = queue[idx];
+                    my_gi = e.gi;
+                    s = e.s;
+                    const uint32_t frame = my_gi / frame_elems;
+                    const uint32_t pix = my_gi - frame * frame_elems;
+                    const int y = (int)(pix / (uint32_t)a.width);
+                    const int x = (int)(pix - (uint32_t)y * (uint32_t)a.width);
+                    const int gy = a.band_rows > 0
+                        ? a.row0 + ((y / a.band_rows) * a.band_stride + a.band_offset) * a.band_rows + (y % a.band_rows)
+                        : a.row0 + y;
+                    FrameParams fp;
+                    if (a.frames) fp = a.frames[frame]; else fp = a.single;
+                    camera_ray(fp.cam, a.width, a.height, x, gy, origin, dir);
+                    cfg.hit_threshold = fp.cfg.hit_threshold;
+                    cfg.max_distance = fp.cfg.max_distance;
+                    cfg.lipschitz = fp.cfg.lipschitz;
+                    cfg.max_iterations = fp.cfg.max_iterations;
+                    active = true;
+                }
+            }
+        }
+        if (!__any(active)) {
+            if (!more) break;
+            continue;
+        }
+
+        // ---- one whole SDF evaluation for every live ray, trips shared by the team -------------------
+        bool ready = true;
+        if (active) ready = Scene::begin(ev, origin + dir * s.te);   // ray.py:15-17
+        while (__any(!ready)) {
+            const bool fin = team_trip<Scene>(ev, !ready, part, lane, xch, turn);
+            if (!ready) ready = fin;
+        }
+        if (active && s.step(Scene::value(ev), cfg)) {
+            active = false;
+            if (part == 0) {
+                const int it = s.res.iters, h = s.res.hit;
+                a.depth[my_gi] = h ? (float)s.res.t : 0.0f;   // types.py:93
+                a.iters[my_gi] = it;
+                a.hit[my_gi] = (uint8_t)h;
+                store_raw(a, my_gi, s.res);
+                acc.add(it, h);
+                atomicAdd(&s_hist[min(it, a.hist_bins - 1)], 1u);
+                if (a.tile_cost) {
+                    const uint32_t frame = my_gi / frame_elems;
+                    const uint32_t pix = my_gi - frame * frame_elems;
+                    const uint32_t y = pix / (uint32_t)a.width, x = pix - y * (uint32_t)a.width;
+                    atomicMax(&a.tile_cost[frame * (uint32_t)a.tiles_per_frame + (y / 4u) * (uint32_t)a.tiles_x + (x >> 6)], it);
+                }
+            }
+        }
+    }
+
+    if (part == 0) acc.flush(a.stats);
+    __syncthreads();
+    for (int b = threadIdx.x; b < kHistBins; b += blockDim.x) {
+        const unsigned int c = s_hist[b];
+        if (c) atomicAdd(&a.stats[kStatsHead + b], (unsigned long long)c);
+    }
+}
+
 // Per-scene launch table, filled by rm_scene_tu.hip (one translation unit per scene).
 struct SceneLaunchers {
     hipError_t (*render)(int strategy, int tile_h, const KernelArgs& a, int grid, hipStream_t s);
     hipError_t (*resume)(int strategy, int level, const KernelArgs& a, int grid, hipStream_t s);
+    hipError_t (*resume_team)(int strategy, int level, const KernelArgs& a, int grid, hipStream_t s);   // nullptr: no team form
     int (*entry_bytes)(int strategy);   // sizeof(QEntry<Strat>)
     hipError_t (*occupancy)(int strategy, int tile_h, int interleave, int* blocks_per_cu);
     hipError_t (*sdf_eval)(const double* xyz, size_t n, double* out, hipStream_t s);
     hipError_t (*march_rays)(int strategy, const MarchCfg& cfg, const double* o, const double* d, size_t n,
                              uint8_t* hit, double* t, int32_t* iters, double* fs, hipStream_t s);
+    hipError_t (*march_rays_team)(int strategy, const MarchCfg& cfg, const double* o, const double* d, size_t n,
+                                  uint8_t* hit, double* t, int32_t* iters, double* fs, hipStream_t s);   // nullptr: no team form
 };
 
 }  // namespace rm

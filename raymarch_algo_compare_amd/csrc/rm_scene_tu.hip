@@ -67,6 +67,22 @@ static hipError_t resume(int strategy, int level, const KernelArgs& a, int grid,
     return hipErrorInvalidValue;
 }
 
+template <bool ITER>
+static hipError_t resume_team_impl(int strategy, int level, const KernelArgs& a, int grid, hipStream_t s)
+{
+    if constexpr (ITER) {
+        switch (strategy) {
+#define RM_X(id, S)                                                                                              \
+    case id:                                                                                                     \
+        hipLaunchKernelGGL((resume_team_kernel<SceneT, S>), dim3(grid), dim3(64 * kTeam), 0, s, a, level);        \
+        return hipGetLastError();
+            RM_STRATEGY_LIST(RM_X)
+#undef RM_X
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
 static int entry_bytes(int strategy)
 {
     switch (strategy) {
@@ -112,12 +128,32 @@ static hipError_t march_rays(int strategy, const MarchCfg& cfg, const double* o,
     return hipErrorInvalidValue;
 }
 
+template <bool ITER>
+static hipError_t march_rays_team_impl(int strategy, const MarchCfg& cfg, const double* o, const double* d, size_t n,
+                                       uint8_t* hit, double* t, int32_t* iters, double* fs, hipStream_t s)
+{
+    if constexpr (ITER) {
+        if (n == 0) return hipSuccess;
+        dim3 grid((unsigned)((n + 63) / 64)), block(64 * kTeam);
+        switch (strategy) {
+#define RM_X(id, S)                                                                                             \
+    case id:                                                                                                    \
+        hipLaunchKernelGGL((march_rays_team_kernel<SceneT, S>), grid, block, 0, s, cfg, o, d, n, hit, t, iters, fs); \
+        return hipGetLastError();
+            RM_STRATEGY_LIST(RM_X)
+#undef RM_X
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
 #define RM_CAT2(a, b) a##b
 #define RM_CAT(a, b) RM_CAT2(a, b)
 // a host function (not a const global: hipcc would try to emit that for the device too)
 const SceneLaunchers* RM_CAT(scene_launchers_, RM_SCENE_ID)()
 {
-    static const SceneLaunchers l = { render, resume, entry_bytes, occupancy, sdf_eval, march_rays };
+    static const SceneLaunchers l = { render, resume, kIter ? resume_team_impl<kIter> : nullptr, entry_bytes, occupancy, sdf_eval, march_rays,
+                                      kIter ? march_rays_team_impl<kIter> : nullptr };
     return &l;
 }
 

@@ -184,6 +184,37 @@ struct SceneMandelbulb {                                                        
         e.r = length(e.z);
         return e.r > 4.0;
     }
+    // ---- the trip split by function, for a TEAM of wavefronts (rm_kernels.h) ----------------------
+    // The three transcendental chains of a trip are independent of one another:
+    //   part 0:  sin, cos of 8 * acos(clamp(z.z / max(r, 1e-12)))            (:277, :286-290)
+    //   part 1:  sin, cos of 8 * atan2(z.y, z.x)                              (:278, :287-289)
+    //   part 2:  r ** 7.0 and r ** 8.0                                        (:280, :283)
+    // trip_part evaluates one of them, trip_join does the rest of the trip from all six values.
+    // trip(e) == trip_join(e, parts 0..2): same expressions, same order, same bits.
+    static RM_HD void trip_part(const Eval& e, int part, double& o0, double& o1)
+    {
+        const double power = 8.0;
+        if (part == 0) {
+            double theta = rm_acos(py_max(-1.0, py_min(1.0, e.z.z / py_max(e.r, 1e-12))));
+            theta *= power;
+            rm_sincos(theta, &o0, &o1);
+        } else if (part == 1) {
+            double phi = rm_atan2(e.z.y, e.z.x);
+            phi *= power;
+            rm_sincos(phi, &o0, &o1);
+        } else {
+            rm_pow2(e.r, power - 1.0, power, &o0, &o1);
+        }
+    }
+    static RM_HD bool trip_join(Eval& e, double st, double ct, double sp, double cp, double r7, double zr)
+    {
+        const double power = 8.0;
+        e.dr = r7 * power * e.dr + 1.0;
+        e.z = v3(zr * st * cp, zr * st * sp, zr * ct) + e.p;
+        if (++e.i >= 8) return true;
+        e.r = length(e.z);
+        return e.r > 4.0;
+    }
     static RM_HD double value(const Eval& e)
     {
         return 0.5 * rm_log(py_max(e.r, 1e-12)) * e.r / py_max(e.dr, 1e-12);

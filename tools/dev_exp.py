@@ -78,11 +78,26 @@ elif exp == "suspend":
             run(sid, kid, repeats=5, warmup=2, suspend_after=sa)
         run(10, 0, W=3840, H=2160, repeats=3, warmup=1, suspend_after=sa)
         run(10, 0, W=7680, H=4320, repeats=3, warmup=1, suspend_after=sa)
-elif exp == "spread":
-    # reserved = resume_waves of level 0 | level 1 << 4
-    for sa in ((32, 128), (32, 96), (48, 128), (32, 192)):
-        for rw in (0x44, 0x14, 0x24, 0x12, 0x22, 0x11):
-            run(10, 0, repeats=7, warmup=2, eval_mode=2, suspend_after=sa, reserved=rw)
+elif exp == "team":
+    import numpy as np
+    scene = registry.SCENES[10]
+    for kid in (0, 5, 9, 10):
+        W, H = 320, 200
+        ref = _native.render(_native.make_desc(10, kid, cam_for(scene, W, H).params14(), W, H, full=True, suspend_after=(-1, -1)), want_t_raw=True, want_final_sdf=True, want_block_var=True)
+        for sa, rv in (((8, 0), 2), ((8, 40), 2), ((32, 128), 2)):
+            o = _native.render(_native.make_desc(10, kid, cam_for(scene, W, H).params14(), W, H, full=True, suspend_after=sa, resume_mode=rv), want_t_raw=True, want_final_sdf=True, want_block_var=True)
+            ok = all(np.array_equal(ref[k].view(np.uint8), o[k].view(np.uint8)) for k in ("depth", "iters", "hit", "t_raw", "final_sdf", "block_var"))
+            ok = ok and all(ref["stats"][k] == o["stats"][k] for k in ("total_rays", "hit_count", "sum_iters", "iter_max", "iter_min")) and np.array_equal(ref["stats"]["iter_hist"], o["stats"]["iter_hist"])
+            print("team resume parity", kid, sa, "OK" if ok else "FAILED", flush=True)
+    for kid in range(11):
+        run(10, kid, repeats=5, warmup=2, suspend_after=(-1, -1))
+        run(10, kid, repeats=5, warmup=2)
+    for W, H in ((960, 540), (2560, 1440), (3840, 2160)):
+        run(10, 0, W=W, H=H, repeats=3, warmup=1, suspend_after=(-1, -1))
+        run(10, 0, W=W, H=H, repeats=3, warmup=1, suspend_after=(32, 128))
+    for sa in ((24, 96), (32, 160), (40, 128), (32, 128)):
+        run(10, 0, repeats=7, warmup=2, suspend_after=sa)
+        run(10, 0, repeats=7, warmup=2, suspend_after=sa, tile_order_mode=1)
 elif exp == "one":
     run(int(sys.argv[2]), int(sys.argv[3]), repeats=int(sys.argv[4]) if len(sys.argv) > 4 else 5)
 elif exp == "matrix":
