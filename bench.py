@@ -2,8 +2,9 @@
 """bench.py -- headline benchmark of the sphere-tracing path on MI355X.
 
 Metric (BASELINE.json): Mrays/s + mean iterations/ray, 1920x1080 Mandelbulb / Standard, fp64
-parity arithmetic, 1/2/4/8 GPUs.  A "step" is one frame render (one launch of the
-(Mandelbulb, Standard) kernel writing depth/iterations/hit into HBM-resident buffers).
+parity arithmetic, 1/2/4/8 GPUs.  A "step" is one frame render into HBM-resident depth / iterations /
+hit buffers: the (Mandelbulb, Standard) render kernel plus the two resume passes that finish the rays it
+parked (long-ray suspension, wavefront teams -- DESIGN.md section 3), all on one stream.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -92,8 +93,8 @@ def main():
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--refill-min", type=int, default=0)
     ap.add_argument("--grid-waves", type=int, default=0)
-    ap.add_argument("--temporal-grid-waves", type=int, default=512,
-                    help="persistent wavefronts for the temporal_order figure (fewer waves = stragglers run alone)")
+    ap.add_argument("--temporal-grid-waves", type=int, default=0,
+                    help="persistent wavefronts for the temporal_order figure (0 = library default)")
     args = ap.parse_args()
 
     import torch
@@ -206,6 +207,21 @@ def main():
     if L.rm_bench_store_path(W, rows_local, ctypes.c_void_p(p_depth.data_ptr()), ctypes.c_void_p(p_iters.data_ptr()),
                              ctypes.c_void_p(p_hit.data_ptr()), ctypes.byref(tm)) == 0 and tm.ms_median > 0:
         store_gbps = BYTES_PER_RAY * rows_local * W / (tm.ms_median * 1e-3) / 1e9
+    # per-pass device time of a frame (events inside the library, between the passes on `stream`): a short
+    # untimed loop after the measurement, so the numbers can be held against the rocprofv3 kernel stats
+    passes = None
+    if L.rm_set_pass_timing(1) == 0:
+        acc_ms, nfr = [0.0] * 3, 5
+        for _ in range(nfr):
+            step()
+            npass = ctypes.c_int32(0)
+            pms = (ctypes.c_float * 3)()
+            _native.check(L.rm_get_pass_ms(sptr, ctypes.byref(npass), pms))
+            for i in range(npass.value):
+                acc_ms[i] += pms[i] / nfr
+        names = ["render_kernel (first pass)", "resume pass 1", "resume pass 2"]
+        passes = {names[i]: acc_ms[i] for i in range(npass.value)}
+        L.rm_set_pass_timing(0)
     kernel_ms = [a.elapsed_time(b) for a, b in evs]
     local = torch.tensor([elapsed, float(st.total_rays), float(st.sum_iters), sum(kernel_ms) / len(kernel_ms)],
                          dtype=torch.float64, device=dev)
@@ -246,11 +262,12 @@ def main():
                        "parallelism": (f"rowshard{world}-bandcyclic4+allgather" if wl["sharded"] else f"frame-per-gpu x{world}")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel_ms_avg": kms, "bytes_per_ray": BYTES_PER_RAY,
+                         "kernel_ms_avg": kms, "passes_ms": passes, "bytes_per_ray": BYTES_PER_RAY,
                          "store_path_GBps": store_gbps,
                          "store_path_frac": (store_gbps / HBM_PEAK_GBPS) if store_gbps else None,
-                         "note": "write-only path, 9 B/ray; the kernel is fp64-VALU / ray-latency bound (DESIGN.md); "
-                                 "store_path_* = the kernel's flush code alone at this frame size"},
+                         "note": "write-only path, 9 B/ray; kernel_ms_avg = device time of one frame (all passes, events on "
+                                 "the launch stream), passes_ms = its kernels one by one; the frame is fp64-VALU / "
+                                 "ray-latency bound (DESIGN.md); store_path_* = the flush code alone at this frame size"},
         }
         # what actually bounds the kernel: fp64 vector work.  530 fp64 flop per fractal iteration
         # (SQ_INSTS_VALU_{FMA,ADD,MUL}_F64 of profiles/, one lane) x 1.76 fractal iterations per SDF

@@ -186,6 +186,15 @@ int rm_bench_device(const RmFrameDesc* desc, void* d_depth, void* d_iters, void*
 int rm_render_batch(const RmFrameDesc* shape, int32_t nframes, const double* cams, const RmMarchConfig* configs,
                     float* depth, int32_t* iters, uint8_t* hit, RmStats* stats, float* ms_total);
 
+/* Per-pass device time of the LAST frame launched (rm_render / rm_render_device / ...): a frame is one
+ * render pass plus, with long-ray suspension, up to two resume passes (RmFrameDesc.suspend_after).
+ * rm_set_pass_timing(1) makes every launch record hipEvents between its passes on the launch stream;
+ * rm_get_pass_ms synchronises that stream and returns the count and the milliseconds of each pass
+ * (ms must hold RM_MAX_PASSES floats). */
+#define RM_MAX_PASSES 3
+int rm_set_pass_timing(int enable);
+int rm_get_pass_ms(void* stream, int32_t* npasses, float* ms);
+
 /* Library-owned device frame buffers for callers without their own allocator. */
 int rm_alloc_frame(int32_t width, int32_t rows, void** d_depth, void** d_iters, void** d_hit);
 int rm_free_frame(void* d_depth, void* d_iters, void* d_hit);

@@ -85,6 +85,11 @@ struct State {
     hipEvent_t ev[2 * RM_MAX_TIMED];
     bool events = false;
     Buf bstats;   // rm_render_batch: the device frame table
+    // optional per-pass timing of the last frame (rm_set_pass_timing): events around the passes
+    bool pass_timing = false;
+    hipEvent_t pev[RM_MAX_PASSES + 1];
+    bool pev_ready = false;
+    int pass_count = 0;
 } g;
 
 std::mutex g_mu;
@@ -110,7 +115,7 @@ int check_desc(const RmFrameDesc* d)
     if (d->tile_rows != 0 && d->tile_rows != 4) return fail(RM_E_BAD_ARG, "tile_rows must be 0 or 4");
     if (d->tile_order_mode < 0 || d->tile_order_mode > 2) return fail(RM_E_BAD_ARG, "tile_order_mode must be 0, 1 or 2");
     if (d->eval_mode < 0 || d->eval_mode > 2) return fail(RM_E_BAD_ARG, "eval_mode must be 0, 1 or 2");
-    if (d->resume_mode < 0 || d->resume_mode > 2) return fail(RM_E_BAD_ARG, "resume_mode must be 0, 1 or 2");
+    if (d->resume_mode < 0 || d->resume_mode > 3) return fail(RM_E_BAD_ARG, "resume_mode must be 0..3");
     if (d->resume_grid < 0) return fail(RM_E_BAD_ARG, "negative resume_grid");
     if (d->band_rows < 0 || d->band_stride < 0 || d->band_offset < 0) return fail(RM_E_BAD_ARG, "negative band parameter");
     if (d->band_rows > 0 && d->band_stride > 1) {
@@ -317,7 +322,11 @@ int launch(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, hipStre
         a.suspend_queue = 0;
         a.block_var = nullptr;      // parked pixels are missing at flush time: reduced from the finished map below
     }
+    const bool pt = g.pass_timing && g.pev_ready;
+    g.pass_count = 0;
+    if (pt) HIP_TRY(hipEventRecord(g.pev[0], s));
     HIP_TRY(rm::scene(d->scene_id)->render(d->strategy_id, tile_h, a, grid, s));
+    if (pt) HIP_TRY(hipEventRecord(g.pev[++g.pass_count], s));
     if (park[0] > 0) {
         rm::KernelArgs b = a;
         b.suspend_after = park[1];
@@ -326,10 +335,11 @@ int launch(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, hipStre
         // one workgroup per compute unit: measured best for both the dense second pass and the sparse last one
         const int rgrid = d->resume_grid > 0 ? d->resume_grid : std::min(grid, g.prop.multiProcessorCount);
         const bool team = rm::scene(d->scene_id)->resume_team != nullptr && d->resume_mode != 1;
-        if (team && park[1] == 0)
+        if (team && (park[1] == 0 || d->resume_mode == 3))
             HIP_TRY(rm::scene(d->scene_id)->resume_team(d->strategy_id, 0, b, rgrid, s));
         else
             HIP_TRY(rm::scene(d->scene_id)->resume(d->strategy_id, 0, b, rgrid, s));
+        if (pt) HIP_TRY(hipEventRecord(g.pev[++g.pass_count], s));
         if (park[1] > 0) {
             b.suspend_after = 0;
             b.interleave = 0;       // a sparse pass of very long rays is latency-bound: whole evaluations per turn
@@ -337,6 +347,7 @@ int launch(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, hipStre
                 HIP_TRY(rm::scene(d->scene_id)->resume_team(d->strategy_id, 1, b, rgrid, s));
             else
                 HIP_TRY(rm::scene(d->scene_id)->resume(d->strategy_id, 1, b, rgrid, s));
+            if (pt) HIP_TRY(hipEventRecord(g.pev[++g.pass_count], s));
         }
         if (block_var) {
             const long long nb = (long long)(a.width >> 3) * (a.rows >> 2) * a.nframes;
@@ -472,6 +483,9 @@ void rm_shutdown(void)
         b->release();
     if (g.events) for (auto& e : g.ev) (void)hipEventDestroy(e);
     g.events = false;
+    if (g.pev_ready) for (auto& e : g.pev) (void)hipEventDestroy(e);
+    g.pev_ready = false;
+    g.pass_timing = false;
 
     (void)hipStreamDestroy(g.stream);
     g.stream = nullptr;
@@ -721,6 +735,33 @@ int rm_render_batch(const RmFrameDesc* shape, int32_t nframes, const double* cam
             }
         }
     }
+    return RM_OK;
+}
+
+int rm_set_pass_timing(int enable)
+{
+    int rc = check_ready();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    HIP_TRY(hipSetDevice(g.device));
+    if (enable && !g.pev_ready) {
+        for (auto& e : g.pev) HIP_TRY(hipEventCreate(&e));
+        g.pev_ready = true;
+    }
+    g.pass_timing = enable != 0;
+    g.pass_count = 0;
+    return RM_OK;
+}
+
+int rm_get_pass_ms(void* stream, int32_t* npasses, float* ms)
+{
+    int rc = check_ready();
+    if (rc) return rc;
+    if (!npasses || !ms) return fail(RM_E_BAD_ARG, "NULL output");
+    if (!g.pass_timing || !g.pev_ready) return fail(RM_E_BAD_ARG, "pass timing is off (rm_set_pass_timing)");
+    HIP_TRY(hipStreamSynchronize(stream ? (hipStream_t)stream : g.stream));
+    *npasses = g.pass_count;
+    for (int i = 0; i < g.pass_count; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], g.pev[i], g.pev[i + 1]));
     return RM_OK;
 }
 

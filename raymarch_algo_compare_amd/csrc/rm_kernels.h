@@ -782,7 +782,11 @@ __global__ __launch_bounds__(64 * kTeam) void resume_team_kernel(const KernelArg
             const bool fin = team_trip<Scene>(ev, !ready, part, lane, xch, turn);
             if (!ready) ready = fin;
         }
-        if (active && s.step(Scene::value(ev), cfg)) {
+        bool park = false;
+        if (active) {
+            if (!s.step(Scene::value(ev), cfg)) {
+                park = a.suspend_after > 0 && s.i >= a.suspend_after;
+            } else {
             active = false;
             if (part == 0) {
                 const int it = s.res.iters, h = s.res.hit;
@@ -798,6 +802,25 @@ __global__ __launch_bounds__(64 * kTeam) void resume_team_kernel(const KernelArg
                     const uint32_t y = pix / (uint32_t)a.width, x = pix - y * (uint32_t)a.width;
                     atomicMax(&a.tile_cost[frame * (uint32_t)a.tiles_per_frame + (y / 4u) * (uint32_t)a.tiles_x + (x >> 6)], it);
                 }
+            }
+            }
+        }
+        if (a.suspend_after > 0 && __any(park)) {
+            // park the longest rays once more: wave 0 reserves the queue slots, every wave learns the outcome
+            const unsigned long long m = __ballot(park);
+            if (part == 0 && lane == 0) s_base = (unsigned int)atomicAdd(&a.stats[6 + a.suspend_queue], (unsigned long long)__popcll(m));
+            __syncthreads();
+            const unsigned int base = (unsigned int)__builtin_amdgcn_readfirstlane((int)s_base);
+            __syncthreads();
+            const unsigned int idx = base + (unsigned int)rank_in_mask(m);
+            if (park && idx < (unsigned int)a.queue_cap) {
+                if (part == 0) {
+                    Entry* e = (Entry*)a.queue[a.suspend_queue] + idx;
+                    e->gi = my_gi;
+                    e->pad = 0;
+                    e->s = s;
+                }
+                active = false;
             }
         }
     }

@@ -1,0 +1,95 @@
+"""Schedules never change results: evaluation mode (whole SDF evaluation vs one trip per turn),
+long-ray suspension (rays parked at a trip budget and resumed from their strategy record) and
+wavefront teams (three waves sharing the trips of the same 64 rays) are checked against the
+reference-generated goldens and against each other, through the C ABI."""
+import numpy as np
+import pytest
+
+from conftest import golden_frames, sha_f64
+from test_gpu_parity import _check, _render
+
+pytestmark = pytest.mark.gpu
+
+# (suspend_after, resume_mode): off / one resume pass / two passes, single waves and teams
+SCHEDULES = [dict(suspend_after=(-1, -1)), dict(suspend_after=(8, 0), resume_mode=1), dict(suspend_after=(8, 0), resume_mode=2),
+             dict(suspend_after=(6, 40), resume_mode=1), dict(suspend_after=(6, 40), resume_mode=2),
+             dict(suspend_after=(6, 40), resume_mode=3), dict()]
+
+
+def test_mandelbulb_every_strategy_every_schedule(hip):
+    """Mandelbulb x 11 strategies (reference goldens, 64x48) under every schedule and both evaluation modes:
+    iterations / hits / raw fp64 t / final_sdf / stats identical to the reference each time."""
+    G = golden_frames("64x48")
+    for kid in range(11):
+        g = G.get(10, kid)
+        for sched in SCHEDULES:
+            for em in (1, 2):
+                out = _render(hip, g, 10, kid, True, eval_mode=em, **sched)
+                assert _check(out, g, 10) == (0, 0), (kid, sched, em)
+
+
+def test_suspension_other_scenes(hip):
+    """Suspension is generic (the strategy record is the march state): algebraic scenes, strategies with
+    multi-evaluation trips (Segment, RevAA, Hybrid, Overstep-Bisect, Slope), goldens at 160x120."""
+    G = golden_frames("160x120")
+    cells = [p for p in G.pairs if p[0] in (0, 9, 11, 12, 13)]
+    assert len(cells) >= 10
+    for sid, kid in cells:
+        g = G.get(sid, kid)
+        for sched in (dict(suspend_after=(4, 0)), dict(suspend_after=(5, 23))):
+            out = _render(hip, g, sid, kid, True, **sched)
+            assert _check(out, g, sid) == (0, 0), (sid, kid, sched)
+
+
+def test_block_var_and_tile_cost_with_parked_rays(hip):
+    """block_var (8x4 divergence numerators) comes from the finished map when rays were parked; the temporal
+    tile order (per-tile cost from the previous frame) keeps working across the resume passes."""
+    g = golden_frames("160x120").get(10, 0)
+    ref = _render(hip, g, 10, 0, False, suspend_after=(-1, -1))
+    it = g["iters"].astype(np.int64)
+    H, W = it.shape
+    blk = it[: H // 4 * 4, : W // 8 * 8].reshape(H // 4, 4, W // 8, 8)
+    want = 32 * (blk * blk).sum(axis=(1, 3)) - blk.sum(axis=(1, 3)) ** 2
+    assert (ref["block_var"] == want).all()
+    for sched in (dict(suspend_after=(8, 0)), dict(suspend_after=(8, 40)), dict(suspend_after=(8, 40), tile_order_mode=1),
+                  dict(suspend_after=(8, 40), tile_order_mode=1)):
+        out = _render(hip, g, 10, 0, False, **sched)
+        assert (out["block_var"] == want).all(), sched
+        assert (out["iters"] == g["iters"]).all() and (out["hit"] == g["hit"]).all()
+
+
+def test_budget_of_one_trip(hip):
+    """A budget of 1 parks every ray that survives its first trip, a budget of 2 parks the survivors again:
+    nearly the whole frame goes through both queues -- results unchanged."""
+    g = golden_frames("64x48").get(10, 4)
+    out = _render(hip, g, 10, 4, True, suspend_after=(1, 2))
+    assert _check(out, g, 10) == (0, 0)
+
+
+def test_march_rays_team_equals_single_wave(hip):
+    """rm_march_rays_team == rm_march_rays bit for bit (explicit rays: every strategy, a frame's worth of
+    rays including the 512-trip stragglers); scenes without a team form are refused."""
+    g = golden_frames("64x48").get(10, 0)
+    cam = g["cam"]
+    W, H = g["W"], g["H"]
+    px, py = np.meshgrid(np.arange(W), np.arange(H))
+    u = (2.0 * (px.ravel() + 0.5) / W - 1.0) * cam[12]
+    v = (1.0 - 2.0 * (py.ravel() + 0.5) / H) * cam[13]
+    dirs = cam[3:6][None, :] + cam[6:9][None, :] * u[:, None] + cam[9:12][None, :] * v[:, None]
+    orig = np.repeat(cam[0:3][None, :], len(dirs), 0)
+    for kid in range(11):
+        a = hip.march_rays(10, kid, orig, dirs)
+        b = hip.march_rays(10, kid, orig, dirs, team=True)
+        for x, y in zip(a, b):
+            assert x.tobytes() == y.tobytes(), kid
+    hit, t, iters, fs = hip.march_rays(10, 0, orig, dirs, team=True)
+    assert (iters.reshape(H, W) == g["iters"]).all() and sha_f64(t.reshape(H, W)) == g["sha_t"]
+    with pytest.raises(hip.RmError):
+        hip.march_rays(0, 0, orig[:4], dirs[:4], team=True)
+
+
+def test_bad_schedule_arguments(hip):
+    g = golden_frames("64x48").get(0, 0)
+    for bad in (dict(eval_mode=3), dict(resume_mode=4), dict(resume_grid=-1)):
+        with pytest.raises(hip.RmError):
+            _render(hip, g, 0, 0, False, **bad)

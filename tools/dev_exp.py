@@ -98,6 +98,11 @@ elif exp == "team":
     for sa in ((24, 96), (32, 160), (40, 128), (32, 128)):
         run(10, 0, repeats=7, warmup=2, suspend_after=sa)
         run(10, 0, repeats=7, warmup=2, suspend_after=sa, tile_order_mode=1)
+elif exp == "team2":
+    for rm_ in (2, 3):
+        for sa in ((32, 128), (32, 96), (24, 96), (32, 64), (16, 64), (48, 128)):
+            for rg in (0, 512):
+                run(10, 0, repeats=7, warmup=2, suspend_after=sa, resume_mode=rm_, resume_grid=rg)
 elif exp == "one":
     run(int(sys.argv[2]), int(sys.argv[3]), repeats=int(sys.argv[4]) if len(sys.argv) > 4 else 5)
 elif exp == "matrix":
