@@ -93,3 +93,48 @@ def test_bad_schedule_arguments(hip):
     for bad in (dict(eval_mode=3), dict(resume_mode=4), dict(resume_grid=-1)):
         with pytest.raises(hip.RmError):
             _render(hip, g, 0, 0, False, **bad)
+
+
+def test_ragged_frames_and_row_shards_with_parked_rays(hip):
+    """Widths that are no multiple of 64 / 8, heights no multiple of 4, row shards and band-cyclic shards:
+    parked rays carry their output index, so every layout must reproduce the oracle frame."""
+    from oracle import oracle
+    from raymarch_algo_compare_amd import registry
+    from raymarch_algo_compare_amd.camera import Camera
+    sc = registry.SCENES[10]
+    for w, h in ((100, 37), (67, 50)):
+        cam = Camera(sc.camera_position, sc.camera_target, (0.0, 1.0, 0.0), 60.0, w, h).params14()
+        ref = oracle.render(10, 0, cam, w, h)
+        for kw in (dict(), dict(row0=8, rows=16), dict(row0=0, rows=12, band_rows=4, band_stride=3, band_offset=1)):
+            for sched in (dict(suspend_after=(5, 30), resume_mode=2), dict(suspend_after=(5, 30), resume_mode=1), dict(suspend_after=(7, 0))):
+                out = hip.render(hip.make_desc(10, 0, cam, w, h, full=True, **kw, **sched), want_t_raw=True, want_final_sdf=True)
+                if "band_rows" in kw:
+                    rows = [kw["row0"] + ((y // 4) * 3 + 1) * 4 + y % 4 for y in range(kw["rows"])]
+                else:
+                    rows = list(range(kw.get("row0", 0), kw.get("row0", 0) + kw.get("rows", h)))
+                assert (out["iters"] == ref.iters[rows]).all() and (out["hit"] == ref.hit[rows]).all(), (w, h, kw, sched)
+                assert (out["t_raw"].view(np.uint64) == ref.t[rows].view(np.uint64)).all(), (w, h, kw, sched)
+                assert (out["final_sdf"].view(np.uint64) == ref.final_sdf[rows].view(np.uint64)).all(), (w, h, kw, sched)
+                assert out["stats"]["sum_iters"] == int(ref.iters[rows].sum())
+
+
+def test_batch_with_parked_rays(hip):
+    """rm_render_batch with suspension: parked rays of different frames share the queues (the entry's output
+    index names the frame; camera and march configuration are looked up per ray on resume)."""
+    import math
+    from raymarch_algo_compare_amd.camera import Camera
+    w, h = 160, 90
+    cams, cfgs = [], []
+    for i in range(6):
+        ang = 2.0 * math.pi * i / 6.0
+        cams.append(Camera((3.0 * math.sin(ang), 0.5 * math.cos(2 * ang), 3.0 * math.cos(ang)), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0),
+                           60.0, w, h).params14())
+        cfgs.append(dict(max_iterations=[512, 200, 77][i % 3], hit_threshold=[1e-4, 1e-3][i % 2], max_distance=100.0, lipschitz=1.0))
+    for kid in (0, 4):
+        for sched in (dict(suspend_after=(6, 40), resume_mode=2), dict(suspend_after=(6, 0), resume_mode=1), dict()):
+            out = hip.render_batch(hip.make_desc(10, kid, cams[0], w, h, **sched), np.array(cams), cfgs)
+            for i in range(6):
+                one = hip.render(hip.make_desc(10, kid, cams[i], w, h, suspend_after=(-1, -1), **cfgs[i]))
+                assert (out["iters"][i] == one["iters"]).all() and (out["hit"][i] == one["hit"]).all(), (kid, sched, i)
+                assert (out["depth"][i].view(np.uint32) == one["depth"].view(np.uint32)).all(), (kid, sched, i)
+                assert out["stats"][i]["sum_iters"] == one["stats"]["sum_iters"]
