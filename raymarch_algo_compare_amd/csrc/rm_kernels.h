@@ -121,7 +121,7 @@ __device__ __forceinline__ void rm_load_tables()
     }
     if constexpr (tb & TB_SINCOS) copy_table(rm_s_sincostab, rm_g_sincostab, 440);
     if constexpr (tb & TB_ACOS) {
-        copy_table(rm_s_asncs, rm_g_asncs, 2568);
+        copy_table(rm_s_asncs, rm_g_asncs, 2808);
         copy_table(rm_s_inroot, rm_g_inroot, 128);
     }
     if constexpr (tb & TB_ATAN) copy_table(rm_s_cij, rm_g_cij, 1687);

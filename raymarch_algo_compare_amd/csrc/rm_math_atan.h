@@ -34,8 +34,8 @@ struct AtanK {
 // Branch-free over the common bands: the Taylor band (|x| < 1/8) and ONE unified table band are
 // always evaluated and selected.  The five table bands of e_asin.c differ only in row stride and
 // polynomial degree (5..9); a band of degree D is evaluated here as a degree-9 Horner chain whose
-// leading coefficients are +0 -- fma(xx, +0, c) == c exactly, so the value is bit-identical to the
-// shorter chain.  The 1/sqrt band (|x| >= 0.96875) is evaluated as well and selected: no branch anywhere.
+// leading coefficients are +0 (stored that way in the re-laid-out table, tools/extract_libm_tables.py)
+// -- fma(xx, +0, c) == c exactly, so the value is bit-identical to the shorter chain.  The 1/sqrt band (|x| >= 0.96875) is evaluated as well and selected: no branch anywhere.
 
 RM_MATH_HD double rm_acos_sqrt_band(double x, int m)          // 0.96875 <= |x| < 1
 {
@@ -87,38 +87,26 @@ RM_MATH_HD double rm_acos(double x)
     const double rt = K::hpi - x;
     const double res_taylor = rt + rm_fnma(pt, x * x2, ((K::hpi - rt) - x) + K::hpi1);
 
-    // 1/8 <= |x| < 0.96875: unified table band
-    const int i13 = (k >> 13) & 0x7f;
-    int n = 11 * ((k >> 15) & 0x1f), deg = 5;
-    const int n5b = 11 * ((k >> 14) & 0x3f) + 352;
-    n = (k >= 0x3fd00000) ? n5b : n;
-    const int n6 = 1056 + 12 * i13, n7 = 992 + 13 * i13, n8 = 884 + 14 * i13, n9 = 768 + 15 * i13;
-    n = (k >= 0x3fe00000) ? n6 : n;  deg = (k >= 0x3fe00000) ? 6 : deg;
-    n = (k >= 0x3fe80000) ? n7 : n;  deg = (k >= 0x3fe80000) ? 7 : deg;
-    n = (k >= 0x3fed8000) ? n8 : n;  deg = (k >= 0x3fed8000) ? 8 : deg;
-    n = (k >= 0x3fee8000) ? n9 : n;  deg = (k >= 0x3fee8000) ? 9 : deg;
-    n = (n > 2568 - 13) ? 2568 - 13 : n;          // keeps the gather in bounds for out-of-band arguments
-    const double* a = rm_asncs + n;
-    // the whole 13-entry row is loaded unconditionally (in bounds by the clamp above), then selected:
-    // a conditional load would come back as a branch
+    // 1/8 <= |x| < 0.96875: table band.  rm_asncs holds 216 uniform rows of 13 doubles (the generator
+    // pads the shorter polynomials of e_asin.c's lower bands with zero leading coefficients):
+    //   rows   0.. 31  |x| < 0.25 (step 2^-5 in the high word's bits 15..19), rows 32..95  |x| < 0.5,
+    //   rows 96..215   0.5 <= |x| < 0.96875, index (k >> 13) & 0x7f
+    const int r1 = (k >> 15) & 0x1f, r2 = 32 + ((k >> 14) & 0x3f), r3 = 96 + ((k >> 13) & 0x7f);
+    int row = (k >= 0x3fd00000) ? r2 : r1;
+    row = (k >= 0x3fe00000) ? r3 : row;
+    row = (row > 215) ? 215 : row;                 // keeps the gather in bounds for out-of-band arguments
+    const double* a = rm_asncs + 13 * row;
     const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5], a6 = a[6], a7 = a[7], a8 = a[8],
-                 a9 = a[9], a10 = a[10], a11 = a[11], a12 = a[12];
+                 a9 = a[9], a10 = a[10], c0 = a[11], cv = a[12];
     const double xx = ax - a0;
-    double p = (deg >= 9) ? a10 : 0.0;
-    p = rm_fma(xx, p, (deg >= 8) ? a9 : 0.0);
-    p = rm_fma(xx, p, (deg >= 7) ? a8 : 0.0);
-    p = rm_fma(xx, p, (deg >= 6) ? a7 : 0.0);
+    double p = rm_fma(xx, a10, a9);                // degree-9 Horner; zero-padded coefficients leave the value unchanged
+    p = rm_fma(xx, p, a8);
+    p = rm_fma(xx, p, a7);
     p = rm_fma(xx, p, a6);
     p = rm_fma(xx, p, a5);
     p = rm_fma(xx, p, a4);
     p = rm_fma(xx, p, a3);
     p = rm_fma(xx, p, a2);
-    // single-level selects only: a nested ?: comes back from the compiler as a branch
-    double c0 = a11, cv = a12;
-    c0 = (deg == 8) ? a10 : c0;  cv = (deg == 8) ? a11 : cv;
-    c0 = (deg == 7) ? a9 : c0;   cv = (deg == 7) ? a10 : cv;
-    c0 = (deg == 6) ? a8 : c0;   cv = (deg == 6) ? a9 : cv;
-    c0 = (deg == 5) ? a7 : c0;   cv = (deg == 5) ? a8 : cv;
     p = rm_fma(xx * xx, p, c0);
     const double t = rm_fma(xx, a1, p);
     const double yb = pos ? (K::hpi - cv) : (cv + K::hpi);

@@ -108,8 +108,26 @@ def main():
         return b"".join(d2b(float.fromhex(h)) for h in hx)
     off = find(blob, anchor_hex("0x1.0400000000000p-3", "0x1.0216988994424p+0", "0x1.0a6a2b799b115p-4"), "asncs", 2568 * 8)
     tab = doubles(blob, off, 2568)
-    parts.append("// asncs (sysdeps/ieee754/dbl-64/asincos.tbl)\n"
-                 "RM_TAB double rm_asncs[2568] = {\n" + fmt_d(tab, 4) + "\n};\n")
+    # Re-laid out as 216 uniform rows of 13 doubles so the device routine needs no per-band selects:
+    #   [x0, a1 .. a6, a7 .. a10 (zero where the band's polynomial is shorter), c0, asin(x0)]
+    # e_asin.c's bands: |x| < 0.25 and < 0.5: degree 5, rows of 11; then degree 6 / 7 / 8 / 9 with rows of
+    # 12 / 13 / 14 / 15.  A zero leading coefficient leaves the Horner value unchanged (fma(t, +0, c) == c).
+    rows = []
+    def add_row(src, deg):
+        a = tab[src:src + deg + 4]
+        rows.extend(list(a[0:7]) + [a[7 + j] if deg >= 6 + j else 0.0 for j in range(4)] + [a[deg + 2], a[deg + 3]])
+    for i in range(32):
+        add_row(11 * i, 5)
+    for i in range(64):
+        add_row(352 + 11 * i, 5)
+    for i in range(120):
+        if i < 64: add_row(1056 + 12 * i, 6)
+        elif i < 108: add_row(992 + 13 * i, 7)
+        elif i < 116: add_row(884 + 14 * i, 8)
+        else: add_row(768 + 15 * i, 9)
+    assert len(rows) == 216 * 13
+    parts.append("// asncs (sysdeps/ieee754/dbl-64/asincos.tbl), uniform rows: x0, a1..a10 (zero-padded), c0, asin(x0)\n"
+                 "RM_TAB double rm_asncs[2808] = {\n" + fmt_d(rows, 13) + "\n};\n")
     # inroot (sysdeps/ieee754/dbl-64/root.tbl): 1/sqrt seeds
     off = find(blob, anchor_hex("0x1.68a1f80d71820p+0", "0x1.65de82af9631fp+0", "0x1.632b1201d39e5p+0"), "inroot", 128 * 8)
     tab = doubles(blob, off, 128)
