@@ -19,7 +19,7 @@ Layout of each frames_*.npz (keys prefixed "s{scene_id}_k{strategy_id}_"):
   cam     float64 (14,)       position, forward, right, up, half_width, half_height
   meta    float64 (8,)        W, H, row0, rows, max_iterations, hit_threshold, max_distance, lipschitz
 
-Usage:  python oracle/gen_golden.py [--only frames64|frames160|rows1080|sdf|stats|leak]
+Usage:  python oracle/gen_golden.py [--only frames64|frames160|rows1080|sdf|stats|leak|viewpoints]
 """
 from __future__ import annotations
 
@@ -171,6 +171,19 @@ def gen_sdf(n=2000):
     np.savez_compressed(os.path.join(OUT, "sdf_points.npz"), **store)
 
 
+def gen_viewpoints():
+    """The reference's curated viewpoints (viewpoints.py:41-140) for every catalogue scene, as data."""
+    from raymarching_benchmark.viewpoints import viewpoints_for
+    from raymarching_benchmark.scenes.catalog import get_all_scenes
+    out = {}
+    for sc in get_all_scenes():
+        out[sc.name] = [[v.name, v.category, [float(c) for c in v.position], [float(c) for c in v.target],
+                         [float(c) for c in v.up]] for v in viewpoints_for(sc)]
+    with open(os.path.join(OUT, "viewpoints.json"), "w", encoding="utf-8") as f:
+        json.dump(out, f, indent=1, ensure_ascii=False)
+    print("viewpoints.json:", sum(len(v) for v in out.values()), "viewpoints of", len(out), "scenes")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="all")
@@ -178,6 +191,8 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     all_pairs = [(s, k) for s in range(len(SCENES)) for k in range(len(STRAT_KEYS))]
     graded9 = [0, 1, 2, 3, 4, 5, 6, 9, 10]  # the README's nine strategies (ids in STRATEGIES order)
+    if a.only in ("all", "viewpoints"):
+        gen_viewpoints()
     if a.only in ("all", "sdf"):
         gen_sdf()
     if a.only in ("all", "frames64"):

@@ -1,0 +1,166 @@
+"""Budget / residual sweeps over the curated viewpoints, one batched launch per (scene, strategy).
+
+The reference's dataset builder (sweep.py:96-283) renders every (scene, strategy, viewpoint, level)
+cell on its own: `budget` mode sweeps max_iterations at a fixed epsilon, `residual` mode sweeps the
+hit threshold at a fixed iteration cap (sweep.py:96-127; default levels sweep.py:48-54).  Small frames
+are bound by the latency of their longest ray, so here all viewpoints x all levels of one (scene,
+strategy) go through ONE rm_render_batch launch (per-frame camera + march configuration, the tails of
+the frames overlap) and the rows are cut from the returned maps on the host.
+
+A row holds the identifiers, the level, the iteration statistics the reference records (mean / median
+/ p95 / max, sweep.py:78-81), its adjacent-pixel divergence proxy (sweep.py:84-93), the hit rate and
+the error against the finest level of the same viewpoint (the finest level stands in for the
+reference's separately rendered ground truth: mean |depth - depth_finest| over common hits and the
+number of pixels whose hit flag differs).  Arithmetic is the CPU path's fp64, so rows are comparable
+with the reference's CPU columns, not with its GLSL column.
+
+    python -m raymarch_algo_compare_amd.sweep --scenes Sphere,Mandelbulb --strategies Standard,Enhanced \
+           --mode budget --width 384 --height 384 --out sweep.csv
+"""
+from __future__ import annotations
+
+import argparse
+import csv
+import json
+import sys
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import registry
+from .camera import Camera
+from .collector import HipCollector
+from .config import MarchConfig
+from .viewpoints import viewpoints_for
+
+DEFAULT_BUDGETS = [32, 64, 128, 256, 512]                       # reference sweep.py:48
+DEFAULT_EPSILONS = [1e-2, 3e-3, 1e-3, 3e-4, 1e-4, 3e-5, 1e-5]   # reference sweep.py:54
+
+ROW_FIELDS = ["scene", "strategy", "viewpoint", "category", "sweep_axis", "level", "max_iterations", "hit_threshold",
+              "width", "height", "iters_mean", "iters_median", "iters_p95", "iters_max", "divergence_proxy", "hit_rate",
+              "depth_mae_vs_finest", "hit_flips_vs_finest", "ms_per_frame"]
+
+
+def build_levels(mode: str, *, budgets: Sequence[int] = DEFAULT_BUDGETS, epsilons: Sequence[float] = DEFAULT_EPSILONS,
+                 cap: int = 512, hit_threshold: float = 1e-4) -> List[Tuple[float, MarchConfig, Dict]]:
+    """(level value, MarchConfig, extra columns) per level -- the reference's two axes (sweep.py:96-127)."""
+    if mode == "budget":
+        return [(float(b), MarchConfig(max_iterations=int(b), hit_threshold=hit_threshold),
+                 {"sweep_axis": "budget", "max_iterations": int(b), "hit_threshold": hit_threshold}) for b in budgets]
+    if mode == "residual":
+        return [(float(e), MarchConfig(max_iterations=int(cap), hit_threshold=float(e)),
+                 {"sweep_axis": "residual", "max_iterations": int(cap), "hit_threshold": float(e)}) for e in epsilons]
+    raise ValueError(f"unknown sweep mode {mode!r}")
+
+
+def divergence_proxy(iters2d: np.ndarray) -> float:
+    """Mean absolute iteration-count difference between adjacent pixels (reference sweep.py:84-93)."""
+    a = np.asarray(iters2d, dtype=np.float64)
+    dx = np.abs(a[:, 1:] - a[:, :-1])
+    dy = np.abs(a[1:, :] - a[:-1, :])
+    n = dx.size + dy.size
+    return float((dx.sum() + dy.sum()) / n) if n else 0.0
+
+
+def finest_index(mode: str, levels) -> int:
+    """The most accurate level of an axis: the largest budget, the smallest epsilon."""
+    vals = [lv[0] for lv in levels]
+    return int(np.argmax(vals)) if mode == "budget" else int(np.argmin(vals))
+
+
+def sweep_cell(collector: HipCollector, scene, strategy, mode: str, levels, width: int, height: int) -> List[Dict]:
+    """All viewpoints x levels of one (scene, strategy) in one batched launch -> one row per frame."""
+    vps = viewpoints_for(scene)
+    cams, cfgs, tags = [], [], []
+    for vp in vps:
+        cam = Camera(vp.position, vp.target, vp.up, 60.0, width, height)
+        for li, (value, mc, extra) in enumerate(levels):
+            cams.append(cam)
+            cfgs.append(mc)
+            tags.append((vp, li, value, extra))
+    frames = collector.benchmark_batch(strategy, scene, cams, cfgs)
+    fin = finest_index(mode, levels)
+    rows = []
+    for i, ((vp, li, value, extra), st) in enumerate(zip(tags, frames)):
+        ref = frames[i - li + fin]                     # finest level of the same viewpoint
+        both = st.hit_map & ref.hit_map
+        it = st.iteration_heatmap
+        rows.append({
+            "scene": scene.name, "strategy": strategy.short_name, "viewpoint": vp.name, "category": vp.category,
+            "sweep_axis": extra["sweep_axis"], "level": value, "max_iterations": extra["max_iterations"],
+            "hit_threshold": extra["hit_threshold"], "width": width, "height": height,
+            "iters_mean": float(it.mean()), "iters_median": float(np.median(it)), "iters_p95": float(np.percentile(it, 95)),
+            "iters_max": float(it.max()), "divergence_proxy": divergence_proxy(it), "hit_rate": float(st.hit_map.mean()),
+            "depth_mae_vs_finest": float(np.abs(st.depth_map[both] - ref.depth_map[both]).mean()) if both.any() else 0.0,
+            "hit_flips_vs_finest": int((st.hit_map != ref.hit_map).sum()),
+            "ms_per_frame": float(st.kernel_ms),
+        })
+    return rows
+
+
+def run_sweep(scene_names: Optional[Sequence[str]] = None, strategy_names: Optional[Sequence[str]] = None, mode: str = "budget",
+              width: int = 384, height: int = 384, budgets: Sequence[int] = DEFAULT_BUDGETS,
+              epsilons: Sequence[float] = DEFAULT_EPSILONS, cap: int = 512, hit_threshold: float = 1e-4,
+              out_path: Optional[str] = None, device_id: int = 0, verbose: bool = False) -> List[Dict]:
+    """Sweep `mode` over the curated viewpoints of the named scenes (default: all 20) for the named
+    strategies (default: all 11).  Unknown names raise KeyError.  Returns the rows; writes CSV (or JSON
+    for a .json path) when `out_path` is given."""
+    scenes = registry.get_all_scenes() if not scene_names else [_need(registry.get_scene_by_name(n), "scene", n) for n in scene_names]
+    strats = ([registry.get_strategy_by_name(k) for k in registry.list_strategies()] if not strategy_names
+              else [_need(registry.get_strategy_by_name(n), "strategy", n) for n in strategy_names])
+    levels = build_levels(mode, budgets=budgets, epsilons=epsilons, cap=cap, hit_threshold=hit_threshold)
+    collector = HipCollector(MarchConfig(), device_id=device_id)
+    rows: List[Dict] = []
+    for scene in scenes:
+        for strat in strats:
+            if strat.has_lipschitz:
+                strat.lipschitz = scene.known_lipschitz_bound() or 1.0      # run_once wiring (reference main.py:58-61)
+            cell = sweep_cell(collector, scene, strat, mode, levels, width, height)
+            rows.extend(cell)
+            if verbose:
+                print(f"{scene.name:24s} {strat.short_name:24s} {len(cell):3d} frames  "
+                      f"{sum(r['ms_per_frame'] for r in cell):8.2f} ms", file=sys.stderr)
+    if out_path:
+        write_rows(rows, out_path)
+    return rows
+
+
+def write_rows(rows: List[Dict], path: str) -> None:
+    if path.lower().endswith(".json"):
+        with open(path, "w", encoding="utf-8") as f:
+            json.dump(rows, f, indent=1, ensure_ascii=False)
+        return
+    with open(path, "w", newline="", encoding="utf-8") as f:
+        w = csv.DictWriter(f, fieldnames=ROW_FIELDS)
+        w.writeheader()
+        w.writerows(rows)
+
+
+def _need(obj, kind, name):
+    if obj is None:
+        raise KeyError(f"unknown {kind} {name!r}")
+    return obj
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--scenes", default="", help="comma-separated scene names (default: all)")
+    ap.add_argument("--strategies", default="", help="comma-separated strategy names (default: all)")
+    ap.add_argument("--mode", default="budget", choices=["budget", "residual"])
+    ap.add_argument("--budgets", default=",".join(map(str, DEFAULT_BUDGETS)))
+    ap.add_argument("--epsilons", default=",".join(map(str, DEFAULT_EPSILONS)))
+    ap.add_argument("--cap", type=int, default=512)
+    ap.add_argument("--hit-threshold", type=float, default=1e-4)
+    ap.add_argument("--width", type=int, default=384)
+    ap.add_argument("--height", type=int, default=384)
+    ap.add_argument("--out", default="sweep.csv")
+    a = ap.parse_args(argv)
+    rows = run_sweep([s for s in a.scenes.split(",") if s], [s for s in a.strategies.split(",") if s], a.mode, a.width, a.height,
+                     [int(v) for v in a.budgets.split(",")], [float(v) for v in a.epsilons.split(",")], a.cap, a.hit_threshold,
+                     a.out, verbose=True)
+    print(f"{len(rows)} rows -> {a.out}")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -104,3 +104,33 @@ def test_non_default_march_configs_match_oracle(hip):
             assert (out["iters"] == ref.iters).all() and (out["hit"] == ref.hit).all(), (sid, kid, mi, thr, far)
             assert (out["t_raw"].view(np.uint64) == ref.t.view(np.uint64)).all(), (sid, kid, mi, thr, far)
             assert (out["final_sdf"].view(np.uint64) == ref.final_sdf.view(np.uint64)).all(), (sid, kid, mi, thr, far)
+
+
+def test_sweep_cells_equal_single_renders(hip, tmp_path):
+    """sweep.run_sweep: every (viewpoint, level) row of a batched (scene, strategy) cell carries the statistics of
+    that frame rendered on its own; both axes; Segment gets the scene's Lipschitz bound like run_once."""
+    from raymarch_algo_compare_amd import sweep, viewpoints
+    w, h = 64, 48
+    rows = sweep.run_sweep(["Sphere", "Mandelbulb", "Bad Lipschitz"], ["Standard", "Segment"], "budget", w, h, budgets=[16, 64, 512],
+                           out_path=str(tmp_path / "sweep.csv"))
+    n_vp = {"Sphere": 2, "Mandelbulb": 3, "Bad Lipschitz Sphere": 1}
+    assert len(rows) == sum(n_vp.values()) * 2 * 3
+    assert len(open(tmp_path / "sweep.csv", encoding="utf-8").read().splitlines()) == len(rows) + 1
+    for r in rows:
+        sc = registry.get_scene_by_name(r["scene"])
+        st = registry.get_strategy_by_name("Segment" if r["strategy"] == "Segment" else "Standard")
+        vp = [v for v in viewpoints.viewpoints_for(sc) if v.name == r["viewpoint"]][0]
+        cam = Camera(vp.position, vp.target, vp.up, 60.0, w, h).params14()
+        lip = (sc.lipschitz or 1.0) if st.key == "Segment" else 1.0
+        one = hip.render(hip.make_desc(sc.id, st.id, cam, w, h, max_iterations=r["max_iterations"],
+                                       hit_threshold=r["hit_threshold"], lipschitz=lip))
+        assert r["iters_mean"] == float(one["iters"].mean()) and r["iters_max"] == float(one["iters"].max()), r
+        assert r["hit_rate"] == float((one["hit"] > 0).mean()) and r["divergence_proxy"] == sweep.divergence_proxy(one["iters"])
+        if r["max_iterations"] == 512:
+            assert r["depth_mae_vs_finest"] == 0.0 and r["hit_flips_vs_finest"] == 0
+    # a tighter budget can only lose hits relative to the finest level on the convex Sphere
+    sph = [r for r in rows if r["scene"] == "Sphere" and r["strategy"] == "Standard" and r["viewpoint"] == "ortho"]
+    assert [r["hit_rate"] for r in sph] == sorted(r["hit_rate"] for r in sph)
+    res = sweep.run_sweep(["Cube"], ["Enhanced"], "residual", w, h, epsilons=[1e-2, 1e-4], cap=200)
+    assert [r["hit_threshold"] for r in res] == [1e-2, 1e-4] * 3 and all(r["max_iterations"] == 200 for r in res)
+    assert all(r["depth_mae_vs_finest"] == 0.0 for r in res if r["hit_threshold"] == 1e-4)
