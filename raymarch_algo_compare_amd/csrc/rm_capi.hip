@@ -695,7 +695,12 @@ int rm_render_batch(const RmFrameDesc* shape, int32_t nframes, const double* cam
     rm::KernelArgs a;
     int tile_h = 0, grid = 0;
     RmFrameDesc d = *shape;
-    if (configs) d.march = configs[0];
+    if (configs) {
+        // the launch-wide scheduling policy (long-ray suspension) looks at the largest budget of the batch
+        d.march = configs[0];
+        for (int f = 1; f < nframes; ++f)
+            if (configs[f].max_iterations > d.march.max_iterations) d.march = configs[f];
+    }
     if ((rc = make_args(&d, (float*)g.depth.p, (int32_t*)g.iters.p, (uint8_t*)g.hit.p, nullptr, nullptr, nullptr,
                         (unsigned long long*)g.stats.p, &a, &tile_h, &grid)))
         return rc;
