@@ -88,7 +88,8 @@ typedef struct RmFrameDesc {
     int32_t resume_grid;   /* 0 = default (one per compute unit); workgroups of the resume passes */
     /* How parked rays are finished.  0 = default (2 where the scene has a team form), 1 = one wavefront per
      * 64 rays, 2 = wavefront TEAMS for the last pass: three waves carry the same 64 rays and each evaluates
-     * one of the three independent transcendental chains of a Mandelbulb trip (rm_march_rays_team). */
+     * one of the three independent transcendental chains of a Mandelbulb trip (rm_march_rays_team), 3 = teams
+     * for both resume passes (measured slower than 2; kept for experiments). */
     int32_t resume_mode;
 } RmFrameDesc;
 
