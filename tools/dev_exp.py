@@ -103,6 +103,10 @@ elif exp == "team2":
         for sa in ((32, 128), (32, 96), (24, 96), (32, 64), (16, 64), (48, 128)):
             for rg in (0, 512):
                 run(10, 0, repeats=7, warmup=2, suspend_after=sa, resume_mode=rm_, resume_grid=rg)
+elif exp == "grid":
+    for sid, kid in ((0, 0), (2, 0), (9, 0), (12, 0), (13, 0), (1, 5), (3, 10), (7, 2), (14, 0), (16, 0), (19, 0), (0, 6)):
+        for gw in (0, 512, 1024, 1536, 2048, 3072, 4096):
+            run(sid, kid, repeats=9, warmup=2, grid_waves=gw)
 elif exp == "one":
     run(int(sys.argv[2]), int(sys.argv[3]), repeats=int(sys.argv[4]) if len(sys.argv) > 4 else 5)
 elif exp == "matrix":
