@@ -175,6 +175,53 @@ def test_plane_and_cube_match_closed_form(hip):
         assert np.median(err) < 2e-4, (kid, float(np.median(err)))
 
 
+def test_thin_torus_matches_the_quartic(hip):
+    """Thin Torus (R = 1.5, r = 0.05, axis y): the smallest positive root of the ray/torus quartic
+    F(t) = (|P|^2 + R^2 - r^2)^2 - 4 R^2 (Px^2 + Pz^2), P = o + t d (the closed form of the reference's
+    gpu/analytic.py:131-192, CPU camera model), on every 5th pixel near the ring."""
+    R, r = 1.5, 0.05
+    pos, d = _rays(3)
+    od = (d * pos).sum(2)
+    dist2 = (pos * pos).sum() - od * od                      # squared distance of the ray line from the centre
+    ys, xs = np.nonzero(dist2 <= (R + r) ** 2 * 1.02)
+    ys, xs = ys[::5], xs[::5]
+    dd = d[ys, xs]
+    s1 = 2.0 * od[ys, xs]
+    s0 = (pos * pos).sum() + R * R - r * r
+    q2 = dd[:, 0] ** 2 + dd[:, 2] ** 2
+    q1 = 2.0 * (pos[0] * dd[:, 0] + pos[2] * dd[:, 2])
+    q0 = pos[0] ** 2 + pos[2] ** 2
+    coef = np.stack([np.ones_like(s1), 2.0 * s1, s1 * s1 + 2.0 * s0 - 4 * R * R * q2, 2.0 * s1 * s0 - 4 * R * R * q1,
+                     s0 * s0 - 4 * R * R * q0 + 0.0 * s1], 1)
+    t_exact = np.full(len(ys), np.inf)
+    gap = np.full(len(ys), np.inf)          # how clearly the ray hits / misses: min |Im| of the nearest root pair
+    for i, c in enumerate(coef):
+        rt = np.roots(c)
+        real = rt[np.abs(rt.imag) < 1e-9].real
+        real = real[real > 1e-6]
+        if real.size:
+            t_exact[i] = real.min()
+        gap[i] = np.abs(rt.imag).min()
+    hit_exact = np.isfinite(t_exact)
+    assert hit_exact.sum() > 1000 and (~hit_exact).sum() > 1000
+    for kid in GRADED:
+        out = _render(hip, 3, kid)
+        hit = out["hit"][ys, xs] > 0
+        t = out["t_raw"][ys, xs]
+        # a marched hit is any point within hit_threshold of the surface: rays passing closer than that are hits too
+        clear_miss = (~hit_exact) & (gap > 2e-2)
+        assert not hit[clear_miss].any(), kid
+        # chords well inside the tube (the two front roots far apart) must be found by the sound strategies
+        ok = hit & hit_exact
+        assert ok.sum() > 0.5 * hit_exact.sum(), (kid, int(ok.sum()), int(hit_exact.sum()))
+        P = pos[None, :] + t[ok][:, None] * dd[ok]
+        sdf = np.sqrt((np.sqrt(P[:, 0] ** 2 + P[:, 2] ** 2) - R) ** 2 + P[:, 1] ** 2) - r     # closed-form distance at the stop
+        assert np.abs(sdf).max() < 1.1e-4, (kid, float(np.abs(sdf).max()))
+        front = ok & (t < t_exact + 0.02)              # stopped on the first sheet of the tube
+        err = np.abs(t[front] - t_exact[front])
+        assert np.median(err) < 3e-4, (kid, float(np.median(err)))
+
+
 def test_8k_frame_smoke(hip):
     """7680x4320 (BASELINE config 5 shape): one band-cyclic rank-0-of-8 shard vs the matching rows of
     a contiguous render of the same image rows."""
