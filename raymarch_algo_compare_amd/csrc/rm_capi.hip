@@ -255,16 +255,18 @@ constexpr long long kQueueCapMax = 1ll << 22;   // entries per suspended-ray que
 // default, < 0 = off, > 0 = explicit.
 void suspend_levels(const RmFrameDesc* d, int ntiles, int* park)
 {
-    // Default: on for Mandelbulb launches of up to ~10 M rays -- those are bound by the latency of a few
-    // hundred 512-trip rays (1080p: 15.2 -> 11.4 ms, 4K: 23.4 -> 21.6 ms); larger launches are
-    // throughput-bound, every other scene's SDF is too cheap for the extra passes to pay, and the
+    // Default: on for Mandelbulb launches of up to ~16 M rays -- those are bound by the latency of a few
+    // hundred 512-trip rays (1080p: 15.2 -> 11.1 ms at 32 / 128 trips; 3840x2160: 22.8 -> 20.2 and
+    // 5120x2880: 30.3 -> 28.4 ms at 48 / 192); larger launches are throughput-bound (7680x4320: 50 ms
+    // without, 53-58 with), every other scene's SDF is too cheap for the extra passes to pay, and the
     // strategies whose rays end early or whose loop index restarts (Overstep-Bisect, Skipping-Spheres,
     // Segment) measured slower with it.
     const long long rays = (long long)ntiles * 256;
     const bool strat_ok = d->strategy_id != 6 && d->strategy_id != 7 && d->strategy_id != 10;
-    const bool dflt = d->scene_id == 10 && strat_ok && rays <= 10000000ll && d->march.max_iterations > 128;
-    park[0] = d->suspend_after[0] > 0 ? d->suspend_after[0] : (d->suspend_after[0] == 0 && dflt ? 32 : 0);
-    park[1] = d->suspend_after[1] > 0 ? d->suspend_after[1] : (d->suspend_after[1] == 0 && dflt && d->suspend_after[0] == 0 ? 128 : 0);
+    const bool dflt = d->scene_id == 10 && strat_ok && rays <= 16000000ll && d->march.max_iterations > 128;
+    const int d0 = rays <= 3000000ll ? 32 : 48, d1 = rays <= 3000000ll ? 128 : 192;
+    park[0] = d->suspend_after[0] > 0 ? d->suspend_after[0] : (d->suspend_after[0] == 0 && dflt ? d0 : 0);
+    park[1] = d->suspend_after[1] > 0 ? d->suspend_after[1] : (d->suspend_after[1] == 0 && dflt && d->suspend_after[0] == 0 ? d1 : 0);
     if (park[0] == 0) park[1] = 0;
     if (park[1] > 0 && park[1] <= park[0]) park[1] = 0;
 }

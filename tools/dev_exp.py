@@ -107,6 +107,10 @@ elif exp == "grid":
     for sid, kid in ((0, 0), (2, 0), (9, 0), (12, 0), (13, 0), (1, 5), (3, 10), (7, 2), (14, 0), (16, 0), (19, 0), (0, 6)):
         for gw in (0, 512, 1024, 1536, 2048, 3072, 4096):
             run(sid, kid, repeats=9, warmup=2, grid_waves=gw)
+elif exp == "big":
+    for W, H in ((3840, 2160), (5120, 2880), (7680, 4320)):
+        for sa in ((-1, -1), (32, 128), (48, 192), (64, 0)):
+            run(10, 0, W=W, H=H, repeats=3, warmup=1, suspend_after=sa)
 elif exp == "one":
     run(int(sys.argv[2]), int(sys.argv[3]), repeats=int(sys.argv[4]) if len(sys.argv) > 4 else 5)
 elif exp == "matrix":
