@@ -259,12 +259,15 @@ void suspend_levels(const RmFrameDesc* d, int ntiles, int* park)
     // hundred 512-trip rays (1080p: 15.2 -> 11.1 ms at 32 / 128 trips; 3840x2160: 22.8 -> 20.2 and
     // 5120x2880: 30.3 -> 28.4 ms at 48 / 192); larger launches are throughput-bound (7680x4320: 50 ms
     // without, 53-58 with), every other scene's SDF is too cheap for the extra passes to pay, and the
-    // strategies whose rays end early or whose loop index restarts (Overstep-Bisect, Skipping-Spheres,
-    // Segment) measured slower with it.
+    // strategies whose rays end early or whose loop index restarts (Overstep-Bisect, Skipping-Spheres)
+    // measured no faster or slower with it.
     const long long rays = (long long)ntiles * 256;
-    const bool strat_ok = d->strategy_id != 6 && d->strategy_id != 7 && d->strategy_id != 10;
+    const bool strat_ok = d->strategy_id != 6 && d->strategy_id != 7;
     const bool dflt = d->scene_id == 10 && strat_ok && rays <= 16000000ll && d->march.max_iterations > 128;
-    const int d0 = rays <= 3000000ll ? 32 : 48, d1 = rays <= 3000000ll ? 128 : 192;
+    // Segment and RevAA evaluate the SDF twice per loop trip: half the trip budgets (Segment 19.7 -> 16.4 ms,
+    // RevAA 22.2 -> 19.5 ms at 16 / 64)
+    const int two = (d->strategy_id == 10 || d->strategy_id == 8) ? 2 : 1;
+    const int d0 = (rays <= 3000000ll ? 32 : 48) / two, d1 = (rays <= 3000000ll ? 128 : 192) / two;
     park[0] = d->suspend_after[0] > 0 ? d->suspend_after[0] : (d->suspend_after[0] == 0 && dflt ? d0 : 0);
     park[1] = d->suspend_after[1] > 0 ? d->suspend_after[1] : (d->suspend_after[1] == 0 && dflt && d->suspend_after[0] == 0 ? d1 : 0);
     if (park[0] == 0) park[1] = 0;

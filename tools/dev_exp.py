@@ -111,6 +111,10 @@ elif exp == "big":
     for W, H in ((3840, 2160), (5120, 2880), (7680, 4320)):
         for sa in ((-1, -1), (32, 128), (48, 192), (64, 0)):
             run(10, 0, W=W, H=H, repeats=3, warmup=1, suspend_after=sa)
+elif exp == "seg":
+    for kid in (10, 8, 7, 6):
+        for sa in ((-1, -1), (16, 64), (16, 48), (24, 96), (32, 128), (8, 32)):
+            run(10, kid, repeats=5, warmup=2, suspend_after=sa)
 elif exp == "one":
     run(int(sys.argv[2]), int(sys.argv[3]), repeats=int(sys.argv[4]) if len(sys.argv) > 4 else 5)
 elif exp == "matrix":
