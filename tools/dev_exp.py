@@ -115,6 +115,20 @@ elif exp == "seg":
     for kid in (10, 8, 7, 6):
         for sa in ((-1, -1), (16, 64), (16, 48), (24, 96), (32, 128), (8, 32)):
             run(10, kid, repeats=5, warmup=2, suspend_after=sa)
+elif exp == "cheap":
+    for sid, kid in ((12, 0), (13, 0), (1, 0), (9, 0), (0, 0), (12, 5), (1, 5), (14, 0), (16, 0)):
+        for sa in ((-1, -1), (64, 0), (96, 0), (128, 0), (192, 0), (96, 256)):
+            run(sid, kid, repeats=7, warmup=2, suspend_after=sa)
+elif exp == "cheap2":
+    for sid in (1, 13):
+        for kid in range(11):
+            for sa in ((-1, -1), (128, 0), (192, 0), (256, 0)):
+                run(sid, kid, repeats=7, warmup=2, suspend_after=sa)
+elif exp == "cheap3":
+    for sid in (0, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 14, 15, 16, 17, 18, 19):
+        for kid in (0, 5, 10, 9):
+            for sa in ((-1, -1), (128, 0)):
+                run(sid, kid, repeats=7, warmup=2, suspend_after=sa)
 elif exp == "one":
     run(int(sys.argv[2]), int(sys.argv[3]), repeats=int(sys.argv[4]) if len(sys.argv) > 4 else 5)
 elif exp == "matrix":
