@@ -271,8 +271,8 @@ void suspend_levels(const RmFrameDesc* d, int ntiles, int* park)
     park[0] = d->suspend_after[0] > 0 ? d->suspend_after[0] : (d->suspend_after[0] == 0 && dflt ? d0 : 0);
     park[1] = d->suspend_after[1] > 0 ? d->suspend_after[1] : (d->suspend_after[1] == 0 && dflt && d->suspend_after[0] == 0 ? d1 : 0);
     // Grazing Plane and Thin Planes Stack: a large share of the frame runs hundreds of trips (whole pixel rows
-    // skim the planes; mean 40-68 trips) and pins the tile slots of the first pass.  Parking at 128 trips turns
-    // those rays into dense wavefronts of their own -- lane compaction: 20-45 % faster for every strategy but
+    // skim the planes; mean 40-68 trips).  Parking at 128 trips turns those rays into dense wavefronts of
+    // their own instead of dragging them along with short rays -- lane compaction: 20-45 % faster for every strategy but
     // Skipping-Spheres (Grazing Plane / Segment 2.16 -> 1.22 ms, Thin Planes / Hybrid 2.23 -> 1.49).  No other
     // scene gains (17 scenes x 4 strategies measured).
     if ((d->scene_id == 1 || d->scene_id == 13) && d->strategy_id != 7 && d->suspend_after[0] == 0 && rays <= 16000000ll &&
