@@ -94,7 +94,8 @@ struct State {
 
 std::mutex g_mu;
 
-constexpr size_t kStatsBytes = sizeof(unsigned long long) * rm::kStatsWords;
+constexpr size_t kStatsBlockBytes = sizeof(unsigned long long) * rm::kStatsWords;   // the canonical block (what the host reads)
+constexpr size_t kStatsBytes = kStatsBlockBytes * rm::kStatsBlocks;                 // + the partial blocks (device buffer size)
 
 int check_ready()
 {
@@ -249,6 +250,20 @@ __global__ void block_var_kernel(const int32_t* __restrict__ iters, int width, i
     out[b] = 32 * Q - S * S;
 }
 
+// Sum the partial stats blocks into the canonical block 0 (totals: add; iter_max and the complemented iter_min: max).
+__global__ void stats_reduce_kernel(unsigned long long* __restrict__ stats)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;      // word index within a block
+    if (w >= rm::kStatsWords || w == 0 || (w >= 6 && w < rm::kStatsHead)) return;   // counters live in block 0 only
+    unsigned long long acc = 0;
+    const bool is_max = (w == 3 || w == 4);
+    for (int p = 1; p <= rm::kStatsParts; ++p) {
+        const unsigned long long v = stats[(size_t)p * rm::kStatsWords + w];
+        acc = is_max ? (v > acc ? v : acc) : acc + v;
+    }
+    stats[w] = acc;
+}
+
 constexpr long long kQueueCapMax = 1ll << 22;   // entries per suspended-ray queue (a full queue leaves rays in place)
 
 // Trip budgets of pass 1 / pass 2 (0 = that pass does not park).  desc->suspend_after: 0 = library
@@ -374,6 +389,8 @@ int launch(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, hipStre
             }
         }
     }
+    hipLaunchKernelGGL(stats_reduce_kernel, dim3((rm::kStatsWords + 255) / 256), dim3(256), 0, s, a.stats);
+    HIP_TRY(hipGetLastError());
     return RM_OK;
 }
 
@@ -624,7 +641,7 @@ int rm_render(const RmFrameDesc* d, float* depth, int32_t* iters, uint8_t* hit, 
         if (block_var && nblk) HIP_TRY(hipMemcpyAsync(block_var, g.bvar.p, nblk * 8, hipMemcpyDeviceToHost, g.stream));
     }
     unsigned long long w[rm::kStatsWords];
-    HIP_TRY(hipMemcpyAsync(w, g.stats.p, kStatsBytes, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipMemcpyAsync(w, g.stats.p, kStatsBlockBytes, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
     if (stats) decode_stats(w, stats);
     return RM_OK;
@@ -652,7 +669,7 @@ int rm_read_stats(const void* d_stats, void* stream, RmStats* out)
     if (!out) return fail(RM_E_BAD_ARG, "out is NULL");
     hipStream_t s = stream ? (hipStream_t)stream : g.stream;
     unsigned long long w[rm::kStatsWords];
-    HIP_TRY(hipMemcpyAsync(w, d_stats ? d_stats : g.stats.p, kStatsBytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(w, d_stats ? d_stats : g.stats.p, kStatsBlockBytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     decode_stats(w, out);
     return RM_OK;
@@ -674,7 +691,7 @@ int rm_bench_device(const RmFrameDesc* d, void* d_depth, void* d_iters, void* d_
     if ((rc = timed_launches(d, a, tile_h, grid, timing))) return rc;
     if (stats) {
         unsigned long long w[rm::kStatsWords];
-        HIP_TRY(hipMemcpy(w, g.stats.p, kStatsBytes, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(w, g.stats.p, kStatsBlockBytes, hipMemcpyDeviceToHost));
         decode_stats(w, stats);
     }
     return RM_OK;

@@ -40,7 +40,7 @@ def test_struct_layout_matches_header():
 def test_registry_sizes():
     lib = _native.load()
     assert lib.rm_num_scenes() == 20 and lib.rm_num_strategies() == 11
-    assert lib.rm_stats_device_bytes() == 8 * (16 + _native.RM_HIST_BINS)
+    assert lib.rm_stats_device_bytes() == 8 * (16 + _native.RM_HIST_BINS) * 65   # canonical block + 64 partial blocks
 
 
 def test_no_cpu_fallback_without_device():
