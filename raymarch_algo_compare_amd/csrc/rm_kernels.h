@@ -24,9 +24,14 @@
 //    only HBM traffic of the path, 9 bytes per ray (4 fp32 depth + 4 int32
 //    iterations + 1 uint8 hit);
 //  * frame statistics ride along: per-wave register accumulators (hit count,
-//    iteration sum/max/min), a per-wave LDS iteration histogram flushed once at
-//    kernel exit, and the reference's 8x4-block "warp divergence" variance
-//    numerators (core/types.py:125-133) reduced in-wave with DPP shuffles.
+//    iteration sum/max/min), a per-workgroup LDS iteration histogram flushed once at
+//    kernel exit into one of 64 partial stats blocks, and the reference's 8x4-block
+//    "warp divergence" variance numerators (core/types.py:125-133) reduced in-wave;
+//  * scenes whose SDF is a data-dependent loop (Mandelbulb) run ONE trip of it per
+//    turn (INTERLEAVE), so lanes with short evaluations do not wait for long ones;
+//  * long rays are parked (strategy record -> queue) and finished by resume_kernel /
+//    resume_team_kernel: dense wavefronts of long rays, and for the longest ones
+//    TEAMS of three wavefronts that split the trip's three transcendental chains.
 #pragma once
 
 #define RM_TABLES_IN_LDS 1   // device math reads the LDS mirror filled by rm_load_tables()
