@@ -652,6 +652,7 @@ int rm_render_device(const RmFrameDesc* d, void* d_depth, void* d_iters, void* d
     if (rc) return rc;
     if ((rc = check_desc(d))) return rc;
     if (!d_depth || !d_iters || !d_hit) return fail(RM_E_BAD_ARG, "device output pointers are required");
+    std::lock_guard<std::mutex> lk(g_mu);     // the enqueue touches the shared workspace (queues, tile order, pass events)
     HIP_TRY(hipSetDevice(g.device));
     rm::KernelArgs a;
     int tile_h = 0, grid = 0;
