@@ -133,6 +133,11 @@ elif exp == "refill":
     for sid, kid in ((0, 0), (2, 0), (9, 0), (12, 0), (13, 0), (1, 5), (7, 2), (16, 0), (19, 0), (5, 0)):
         for rm_ in (4, 8, 16, 24, 32, 48):
             run(sid, kid, repeats=9, warmup=2, refill_min=rm_)
+elif exp == "exp2":
+    for sid in (14, 15, 16, 19):
+        for kid in (0, 5):
+            for sa in ((-1, -1), (24, 0), (32, 0), (48, 0), (32, 128), (64, 0)):
+                run(sid, kid, repeats=5, warmup=2, suspend_after=sa)
 elif exp == "one":
     run(int(sys.argv[2]), int(sys.argv[3]), repeats=int(sys.argv[4]) if len(sys.argv) > 4 else 5)
 elif exp == "matrix":
