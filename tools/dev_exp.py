@@ -138,6 +138,11 @@ elif exp == "exp2":
         for kid in (0, 5):
             for sa in ((-1, -1), (24, 0), (32, 0), (48, 0), (32, 128), (64, 0)):
                 run(sid, kid, repeats=5, warmup=2, suspend_after=sa)
+elif exp == "cheap4":
+    for sid in (0, 3, 5, 7, 8, 9, 12, 2, 4):
+        for kid in (0, 5):
+            for sa in ((-1, -1), (24, 0), (32, 0), (48, 0), (64, 0), (96, 0)):
+                run(sid, kid, repeats=7, warmup=2, suspend_after=sa)
 elif exp == "one":
     run(int(sys.argv[2]), int(sys.argv[3]), repeats=int(sys.argv[4]) if len(sys.argv) > 4 else 5)
 elif exp == "matrix":
