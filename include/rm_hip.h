@@ -187,6 +187,11 @@ int rm_bench_device(const RmFrameDesc* desc, void* d_depth, void* d_iters, void*
 int rm_render_batch(const RmFrameDesc* shape, int32_t nframes, const double* cams, const RmMarchConfig* configs,
                     float* depth, int32_t* iters, uint8_t* hit, RmStats* stats, float* ms_total);
 
+/* Entries each of the two parked-ray queues may hold (device memory: entries x 64..136 bytes, allocated on
+ * first use; default 4 Mi, 0 restores it).  A ray that finds the queue full simply marches on where it is,
+ * so the capacity bounds memory, never results. */
+int rm_set_queue_capacity(int64_t entries);
+
 /* Per-pass device time of the LAST frame launched (rm_render / rm_render_device / ...): a frame is one
  * render pass plus, with long-ray suspension, up to two resume passes (RmFrameDesc.suspend_after).
  * rm_set_pass_timing(1) makes every launch record hipEvents between its passes on the launch stream;

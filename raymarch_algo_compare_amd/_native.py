@@ -25,7 +25,7 @@ EXPORTS = [
     "rm_init", "rm_shutdown", "rm_last_error", "rm_device_info", "rm_num_scenes", "rm_num_strategies",
     "rm_sdf_eval", "rm_march_rays", "rm_march_rays_team", "rm_render", "rm_render_device", "rm_stats_device_bytes",
     "rm_read_stats", "rm_bench_device", "rm_alloc_frame", "rm_free_frame", "rm_copy_frame_to_host",
-    "rm_bench_store_path", "rm_render_batch", "rm_set_pass_timing", "rm_get_pass_ms",
+    "rm_bench_store_path", "rm_render_batch", "rm_set_pass_timing", "rm_get_pass_ms", "rm_set_queue_capacity",
 ]
 
 
@@ -113,6 +113,7 @@ def load() -> ctypes.CDLL:
         L.rm_copy_frame_to_host.argtypes = [ctypes.c_int32, ctypes.c_int32, vp, vp, vp, vp, vp, vp]
         L.rm_bench_store_path.argtypes = [ctypes.c_int32, ctypes.c_int32, vp, vp, vp, ctypes.POINTER(RmTiming)]
         L.rm_set_pass_timing.argtypes = [ctypes.c_int]
+        L.rm_set_queue_capacity.argtypes = [ctypes.c_int64]
         L.rm_get_pass_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_float)]
         for name in EXPORTS:
             if name not in ("rm_shutdown", "rm_last_error", "rm_stats_device_bytes"):

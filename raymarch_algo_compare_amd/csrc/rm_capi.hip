@@ -263,7 +263,8 @@ __global__ void stats_reduce_kernel(unsigned long long* __restrict__ stats)
     stats[w] = acc;
 }
 
-constexpr long long kQueueCapMax = 1ll << 22;   // entries per suspended-ray queue (a full queue leaves rays in place)
+constexpr long long kQueueCapMax = 1ll << 22;   // default entries per suspended-ray queue (a full queue leaves rays in place)
+long long g_queue_cap = kQueueCapMax;           // rm_set_queue_capacity
 
 // Trip budgets of pass 1 / pass 2 (0 = that pass does not park).  desc->suspend_after: 0 = library
 // default, < 0 = off, > 0 = explicit.
@@ -343,7 +344,7 @@ int launch(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, hipStre
     long long* const block_var = a.block_var;
     if (park[0] > 0) {
         const long long total = (long long)a.rows * a.width * a.nframes;
-        const long long cap = std::min<long long>(total, kQueueCapMax);
+        const long long cap = std::min<long long>(total, g_queue_cap);
         const int stride = rm::scene(d->scene_id)->entry_bytes(d->strategy_id);
         int rc;
         for (int q = 0; q < (park[1] > 0 ? 2 : 1); ++q) {
@@ -778,6 +779,14 @@ int rm_render_batch(const RmFrameDesc* shape, int32_t nframes, const double* cam
             }
         }
     }
+    return RM_OK;
+}
+
+int rm_set_queue_capacity(int64_t entries)
+{
+    if (entries < 0) return fail(RM_E_BAD_ARG, "negative queue capacity");
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_queue_cap = entries == 0 ? kQueueCapMax : std::min<long long>(entries, 1ll << 30);
     return RM_OK;
 }
 

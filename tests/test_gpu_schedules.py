@@ -138,3 +138,23 @@ def test_batch_with_parked_rays(hip):
                 assert (out["iters"][i] == one["iters"]).all() and (out["hit"][i] == one["hit"]).all(), (kid, sched, i)
                 assert (out["depth"][i].view(np.uint32) == one["depth"].view(np.uint32)).all(), (kid, sched, i)
                 assert out["stats"][i]["sum_iters"] == one["stats"]["sum_iters"]
+
+
+def test_full_queue_leaves_rays_in_place(hip):
+    """rm_set_queue_capacity bounds the parked-ray queues; rays that find them full march on in their lanes.
+    100 entries against ~10 000 rays that want to park (twice): results unchanged."""
+    G = golden_frames("160x120")
+    L = hip.load()
+    try:
+        hip.check(L.rm_set_queue_capacity(100))
+        for kid in (0, 4, 6):
+            g = G.get(10, kid)
+            for sched in (dict(suspend_after=(2, 9), resume_mode=2), dict(suspend_after=(3, 0), resume_mode=1), dict(suspend_after=(2, 9), resume_mode=3)):
+                out = _render(hip, g, 10, kid, True, **sched)
+                assert _check(out, g, 10) == (0, 0), (kid, sched)
+        g = G.get(12, 0)
+        assert _check(_render(hip, g, 12, 0, True, suspend_after=(3, 11)), g, 12) == (0, 0)
+    finally:
+        hip.check(L.rm_set_queue_capacity(0))
+    with pytest.raises(hip.RmError):
+        hip.check(L.rm_set_queue_capacity(-1))
