@@ -162,7 +162,8 @@ int make_args(const RmFrameDesc* d, float* depth, int32_t* iters, uint8_t* hit, 
     // measured best or equal on every scene (Pillar Forest 1.93 -> 1.69 ms against the 24 used earlier)
     a->refill_min = (d->refill_min > 0 && d->refill_min <= 64) ? d->refill_min : 8;
     a->hist_bins = rm::kHistBins;
-    a->interleave = d->eval_mode != 1;
+    // one trip per turn pays where the trip count varies (Mandelbulb); the one-trip union scenes run whole evaluations
+    a->interleave = d->eval_mode == 2 || (d->eval_mode == 0 && d->scene_id == 10);
     if (d->band_rows > 0 && d->band_stride > 1) {
         a->band_rows = d->band_rows; a->band_stride = d->band_stride; a->band_offset = d->band_offset;
     }
@@ -293,6 +294,12 @@ void suspend_levels(const RmFrameDesc* d, int ntiles, int* park)
     if ((d->scene_id == 1 || d->scene_id == 13) && d->strategy_id != 7 && d->suspend_after[0] == 0 && rays <= 16000000ll &&
         d->march.max_iterations > 128)
         park[0] = 128;
+    // Sphere Cloud and Bumpy Sphere (unions of 24 / 31 spheres: a pow per sphere and evaluation).  The long rays are
+    // parked at 16 trips and finished by TEAMS, each wave taking a third of the sphere list: 4.03 -> 3.2 ms and
+    // 6.5 -> 5.2 ms (Curvature 7.9 -> 5.7).
+    if ((d->scene_id == 14 || d->scene_id == 15) && strat_ok && d->suspend_after[0] == 0 && rays <= 16000000ll &&
+        d->march.max_iterations > 128)
+        park[0] = 16 / two;
     // Gyroid (three sincos per evaluation, long skimming rays inside the ball): parking at 24 trips measured
     // 1.82 -> 1.63 ms (Standard) and 2.29 -> 1.98 ms (Curvature); Sphere Cloud, Bumpy Sphere, Metaballs lose.
     if (d->scene_id == 16 && strat_ok && d->suspend_after[0] == 0 && rays <= 16000000ll && d->march.max_iterations > 128)

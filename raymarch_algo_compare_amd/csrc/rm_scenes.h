@@ -251,19 +251,31 @@ struct SceneThinPlanes {                                                        
 
 // (center, radius) tables of Sphere Cloud (:401-414) and Bumpy Sphere (:450-461).
 // Written as unrolled literal lists so they live in the instruction stream / SGPRs.
-#define RM_CLOUD_LIST(X)                                                                   \
+#define RM_CLOUD_LIST_A(X)                                                                 \
     X(0.4253, 1.3505, 0.9373, 0.4723) X(-0.9343, -0.6794, 1.2701, 0.4257)                 \
     X(-1.6821, 1.0922, 1.0100, 0.3090) X(-0.1090, -0.6697, -0.7534, 0.4659)               \
     X(-0.8334, -0.1867, 0.0155, 0.4879) X(0.1819, 1.6847, 0.9951, 0.4789)                 \
-    X(0.4154, 1.6625, -0.9680, 0.4053) X(-1.1553, 0.3826, -1.5506, 0.3120)                \
+    X(0.4154, 1.6625, -0.9680, 0.4053) X(-1.1553, 0.3826, -1.5506, 0.3120)
+#define RM_CLOUD_LIST_B(X)                                                                 \
     X(-1.5787, 0.0506, -0.1149, 0.3223) X(1.4184, 0.4394, 0.0480, 0.4841)                 \
     X(-0.0106, -0.8584, -1.6599, 0.4015) X(-1.0458, 0.6529, -1.0179, 0.3197)              \
     X(-0.4436, -1.6873, 1.1222, 0.4745) X(-1.1748, -0.7902, 1.2931, 0.4211)               \
-    X(0.0333, 1.1803, 0.4750, 0.4053) X(0.8220, -1.3889, 0.1399, 0.3628)                  \
+    X(0.0333, 1.1803, 0.4750, 0.4053) X(0.8220, -1.3889, 0.1399, 0.3628)
+#define RM_CLOUD_LIST_C(X)                                                                 \
     X(0.0264, 1.2626, -0.4717, 0.3704) X(0.3338, -1.4985, -0.3821, 0.3327)                \
     X(-0.6017, -1.1893, 1.0755, 0.2884) X(-0.4099, 1.6277, 0.3060, 0.4728)                \
     X(0.3572, 0.4692, 0.5999, 0.3829) X(-1.1873, -0.2029, -0.8855, 0.4005)                \
     X(-0.3315, -1.3712, 1.5906, 0.3509) X(-0.9690, 0.5840, -0.6786, 0.4453)
+#define RM_CLOUD_LIST(X) RM_CLOUD_LIST_A(X) RM_CLOUD_LIST_B(X) RM_CLOUD_LIST_C(X)
+
+// A union of many primitives is a flat evaluation, but its terms are independent: for a TEAM of wavefronts
+// (rm_kernels.h) it is written like a one-trip resumable SDF whose trip splits three ways -- every wave takes
+// the minimum over a third of the list, trip_join takes the minimum of the three.  min is exact and
+// associative on these values (no NaN, and length(...) - r never yields -0.0), so the result has the same bits.
+struct UnionEval {
+    vec3 p;
+    double d;
+};
 
 struct SceneSphereCloud {                                                                // :424-428
     static RM_HD double sdf(vec3 p)
@@ -274,19 +286,42 @@ struct SceneSphereCloud {                                                       
 #undef RM_X
         return d;
     }
+    using Eval = UnionEval;
+    static RM_HD bool begin(Eval& e, vec3 p) { e.p = p; return false; }
+    static RM_HD bool trip(Eval& e) { e.d = sdf(e.p); return true; }
+    static RM_HD double value(const Eval& e) { return e.d; }
+    static RM_HD void trip_part(const Eval& e, int part, double& o0, double& o1)
+    {
+        const vec3 p = e.p;
+        double d = 1e10;
+#define RM_X(cx, cy, cz, r) d = py_min(d, sd_sphere(p - v3(cx, cy, cz), r));
+        if (part == 0) { RM_CLOUD_LIST_A(RM_X) } else if (part == 1) { RM_CLOUD_LIST_B(RM_X) } else { RM_CLOUD_LIST_C(RM_X) }
+#undef RM_X
+        o0 = d; o1 = 0.0;
+    }
+    static RM_HD bool trip_join(Eval& e, double a, double, double b, double, double c, double)
+    {
+        e.d = py_min(py_min(a, b), c);
+        return true;
+    }
 };
 
-#define RM_BUMP_LIST(X)                                                                    \
+#define RM_BUMP_LIST_A(X)                                                                  \
     X(0.3841, 1.4500, 0.0000) X(-0.4821, 1.3500, 0.4417) X(0.0725, 1.2500, -0.8260)       \
     X(0.5860, 1.1500, 0.7643) X(-1.0548, 1.0500, -0.1866) X(0.9794, 0.9500, -0.6230)      \
     X(-0.3209, 0.8500, 1.1935) X(-0.5987, 0.7500, -1.1528) X(1.2698, 0.6500, 0.4637)      \
-    X(-1.2900, 0.5500, 0.5325) X(0.6065, 0.4500, -1.2960) X(0.4365, 0.3500, 1.3917)       \
+    X(-1.2900, 0.5500, 0.5325)
+#define RM_BUMP_LIST_B(X)                                                                  \
+    X(0.6065, 0.4500, -1.2960) X(0.4365, 0.3500, 1.3917)                                  \
     X(-1.2797, 0.2500, -0.7416) X(1.4577, 0.1500, -0.3205) X(-0.8622, 0.0500, 1.2264)     \
     X(-0.1927, -0.0500, -1.4867) X(1.1412, -0.1500, 0.9618) X(-1.4778, -0.2500, 0.0611)   \
-    X(1.0339, -0.3500, -1.0289) X(-0.0661, -0.4500, 1.4294) X(-0.8941, -0.5500, -1.0715)  \
+    X(1.0339, -0.3500, -1.0289) X(-0.0661, -0.4500, 1.4294)
+#define RM_BUMP_LIST_C(X)                                                                  \
+    X(-0.8941, -0.5500, -1.0715)                                                          \
     X(1.3398, -0.6500, 0.1803) X(-1.0663, -0.7500, 0.7419) X(0.2713, -0.8500, -1.2058)    \
     X(0.5771, -0.9500, 1.0072) X(-1.0205, -1.0500, -0.3256) X(0.8743, -1.1500, -0.4039)   \
     X(-0.3201, -1.2500, 0.7649) X(-0.2213, -1.3500, -0.6152) X(0.3400, -1.4500, 0.1787)
+#define RM_BUMP_LIST(X) RM_BUMP_LIST_A(X) RM_BUMP_LIST_B(X) RM_BUMP_LIST_C(X)
 
 struct SceneBumpySphere {                                                                // :471-475
     static RM_HD double sdf(vec3 p)
@@ -296,6 +331,24 @@ struct SceneBumpySphere {                                                       
         RM_BUMP_LIST(RM_X)
 #undef RM_X
         return d;
+    }
+    using Eval = UnionEval;
+    static RM_HD bool begin(Eval& e, vec3 p) { e.p = p; return false; }
+    static RM_HD bool trip(Eval& e) { e.d = sdf(e.p); return true; }
+    static RM_HD double value(const Eval& e) { return e.d; }
+    static RM_HD void trip_part(const Eval& e, int part, double& o0, double& o1)
+    {
+        const vec3 p = e.p;
+        double d = 1e10;
+#define RM_X(cx, cy, cz) d = py_min(d, sd_sphere(p - v3(cx, cy, cz), 0.18));
+        if (part == 0) { d = sd_sphere(p, 1.4); RM_BUMP_LIST_A(RM_X) } else if (part == 1) { RM_BUMP_LIST_B(RM_X) } else { RM_BUMP_LIST_C(RM_X) }
+#undef RM_X
+        o0 = d; o1 = 0.0;
+    }
+    static RM_HD bool trip_join(Eval& e, double a, double, double b, double, double c, double)
+    {
+        e.d = py_min(py_min(a, b), c);
+        return true;
     }
 };
 
@@ -354,6 +407,8 @@ struct SceneMetaballs {                                                         
 
 template <> struct SceneTables<SceneMandelbulb> { static constexpr unsigned value = TB_POW | TB_SINCOS | TB_ACOS | TB_ATAN | TB_LOG; };
 template <> struct SceneIterative<SceneMandelbulb> { static constexpr bool value = true; };
+template <> struct SceneIterative<SceneSphereCloud> { static constexpr bool value = true; };    // one trip, splits three ways
+template <> struct SceneIterative<SceneBumpySphere> { static constexpr bool value = true; };
 template <> struct SceneTables<SceneGyroid> { static constexpr unsigned value = TB_POW | TB_SINCOS; };
 
 #define RM_NUM_SCENES 20

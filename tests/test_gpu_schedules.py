@@ -158,3 +158,27 @@ def test_full_queue_leaves_rays_in_place(hip):
         hip.check(L.rm_set_queue_capacity(0))
     with pytest.raises(hip.RmError):
         hip.check(L.rm_set_queue_capacity(-1))
+
+
+def test_union_scenes_team_form(hip):
+    """Sphere Cloud / Bumpy Sphere: a team evaluates the union three ways (each wave a third of the sphere
+    list, minimum of the three).  Goldens at 64x48 for every strategy under single-wave and team schedules,
+    and rm_march_rays_team against rm_march_rays."""
+    G = golden_frames("64x48")
+    for sid in (14, 15):
+        for kid in range(11):
+            g = G.get(sid, kid)
+            for sched in (dict(suspend_after=(-1, -1)), dict(suspend_after=(4, 0), resume_mode=2), dict(suspend_after=(4, 19), resume_mode=2),
+                          dict(suspend_after=(4, 19), resume_mode=3), dict(suspend_after=(5, 0), resume_mode=1), dict(eval_mode=2), dict()):
+                out = _render(hip, g, sid, kid, True, **sched)
+                assert _check(out, g, sid) == (0, 0), (sid, kid, sched)
+        g = G.get(sid, 0)
+        cam, W, H = g["cam"], g["W"], g["H"]
+        px, py = np.meshgrid(np.arange(W), np.arange(H))
+        u = (2.0 * (px.ravel() + 0.5) / W - 1.0) * cam[12]
+        v = (1.0 - 2.0 * (py.ravel() + 0.5) / H) * cam[13]
+        dirs = cam[3:6][None, :] + cam[6:9][None, :] * u[:, None] + cam[9:12][None, :] * v[:, None]
+        orig = np.repeat(cam[0:3][None, :], len(dirs), 0)
+        a, b = hip.march_rays(sid, 0, orig, dirs), hip.march_rays(sid, 0, orig, dirs, team=True)
+        assert all(x.tobytes() == y.tobytes() for x, y in zip(a, b))
+        assert (b[2].reshape(H, W) == g["iters"]).all()

@@ -143,6 +143,21 @@ elif exp == "cheap4":
         for kid in (0, 5):
             for sa in ((-1, -1), (24, 0), (32, 0), (48, 0), (64, 0), (96, 0)):
                 run(sid, kid, repeats=7, warmup=2, suspend_after=sa)
+elif exp == "union":
+    import numpy as np
+    for sid in (14, 15):
+        scene = registry.SCENES[sid]
+        W, H = 320, 200
+        for kid in (0, 5, 10):
+            ref = _native.render(_native.make_desc(sid, kid, cam_for(scene, W, H).params14(), W, H, full=True, suspend_after=(-1, -1), eval_mode=1), want_t_raw=True, want_final_sdf=True, want_block_var=True)
+            for kw in (dict(suspend_after=(8, 0), resume_mode=2), dict(suspend_after=(8, 40), resume_mode=2), dict(suspend_after=(8, 40), resume_mode=1), dict(eval_mode=2, suspend_after=(-1, -1)), dict(suspend_after=(6, 30), resume_mode=3)):
+                o = _native.render(_native.make_desc(sid, kid, cam_for(scene, W, H).params14(), W, H, full=True, **kw), want_t_raw=True, want_final_sdf=True, want_block_var=True)
+                ok = all(np.array_equal(ref[k].view(np.uint8), o[k].view(np.uint8)) for k in ("depth", "iters", "hit", "t_raw", "final_sdf", "block_var"))
+                print("union team parity", sid, kid, kw, "OK" if ok else "FAILED", flush=True)
+    for sid in (14, 15):
+        for kid in (0, 5):
+            for sa in ((-1, -1), (16, 0), (24, 0), (32, 0), (48, 0), (32, 128), (24, 96)):
+                run(sid, kid, repeats=5, warmup=2, suspend_after=sa)
 elif exp == "one":
     run(int(sys.argv[2]), int(sys.argv[3]), repeats=int(sys.argv[4]) if len(sys.argv) > 4 else 5)
 elif exp == "matrix":
