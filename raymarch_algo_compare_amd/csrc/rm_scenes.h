@@ -353,19 +353,23 @@ struct SceneBumpySphere {                                                       
 };
 
 struct SceneGyroid {                                                                     // :496-517
+    static constexpr double FREQ = 3.0;
+    static constexpr double LIP = 0x1.4c8dc2e423980p+3;  // 3.0 * 2.0 * (3.0 ** 0.5) as CPython evaluates it
+    static RM_HD double combine(vec3 p, double sx, double cx, double sy, double cy, double sz, double cz)
+    {
+        double g = sx * cy + sy * cz + sz * cx;
+        double sheet = g / LIP;
+        double ball = sd_sphere(p, 2.2);
+        return py_max(sheet, ball);
+    }
     static RM_HD double sdf(vec3 p)
     {
-        const double FREQ = 3.0;
-        const double LIP = 0x1.4c8dc2e423980p+3;  // 3.0 * 2.0 * (3.0 ** 0.5) as CPython evaluates it
         double qx = FREQ * p.x, qy = FREQ * p.y, qz = FREQ * p.z;
         double sx, cx, sy, cy, sz, cz;
         rm_sincos(qx, &sx, &cx);
         rm_sincos(qy, &sy, &cy);
         rm_sincos(qz, &sz, &cz);
-        double g = sx * cy + sy * cz + sz * cx;
-        double sheet = g / LIP;
-        double ball = sd_sphere(p, 2.2);
-        return py_max(sheet, ball);
+        return combine(p, sx, cx, sy, cy, sz, cz);
     }
 };
 

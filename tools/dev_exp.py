@@ -158,6 +158,11 @@ elif exp == "union":
         for kid in (0, 5):
             for sa in ((-1, -1), (16, 0), (24, 0), (32, 0), (48, 0), (32, 128), (24, 96)):
                 run(sid, kid, repeats=5, warmup=2, suspend_after=sa)
+elif exp == "gyroid":
+    for kid in (0, 5, 10, 4):
+        for sa in ((-1, -1), (16, 0), (24, 0), (32, 0), (48, 0)):
+            for rm_ in (1, 2):
+                run(16, kid, repeats=5, warmup=2, suspend_after=sa, resume_mode=rm_)
 elif exp == "one":
     run(int(sys.argv[2]), int(sys.argv[3]), repeats=int(sys.argv[4]) if len(sys.argv) > 4 else 5)
 elif exp == "matrix":
