@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Developer experiments on a GPU box (not product, not tests): where does Mandelbulb/Standard
-1080p spend its time?  Usage: python tools/dev_exp.py <exp> ..."""
+"""Developer experiments on a GPU box (not product, not tests): the sweeps behind the scheduling defaults
+(DESIGN.md section 3).  Usage: python tools/dev_exp.py <exp> ...   exp = budget | interleave | suspend | team |
+grid | big | seg | planes | survey | refill | union | one <scene> <strategy> [repeats] | matrix | batch"""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raymarch_algo_compare_amd import _native, registry
@@ -98,11 +99,6 @@ elif exp == "team":
     for sa in ((24, 96), (32, 160), (40, 128), (32, 128)):
         run(10, 0, repeats=7, warmup=2, suspend_after=sa)
         run(10, 0, repeats=7, warmup=2, suspend_after=sa, tile_order_mode=1)
-elif exp == "team2":
-    for rm_ in (2, 3):
-        for sa in ((32, 128), (32, 96), (24, 96), (32, 64), (16, 64), (48, 128)):
-            for rg in (0, 512):
-                run(10, 0, repeats=7, warmup=2, suspend_after=sa, resume_mode=rm_, resume_grid=rg)
 elif exp == "grid":
     for sid, kid in ((0, 0), (2, 0), (9, 0), (12, 0), (13, 0), (1, 5), (3, 10), (7, 2), (14, 0), (16, 0), (19, 0), (0, 6)):
         for gw in (0, 512, 1024, 1536, 2048, 3072, 4096):
@@ -115,16 +111,12 @@ elif exp == "seg":
     for kid in (10, 8, 7, 6):
         for sa in ((-1, -1), (16, 64), (16, 48), (24, 96), (32, 128), (8, 32)):
             run(10, kid, repeats=5, warmup=2, suspend_after=sa)
-elif exp == "cheap":
-    for sid, kid in ((12, 0), (13, 0), (1, 0), (9, 0), (0, 0), (12, 5), (1, 5), (14, 0), (16, 0)):
-        for sa in ((-1, -1), (64, 0), (96, 0), (128, 0), (192, 0), (96, 256)):
-            run(sid, kid, repeats=7, warmup=2, suspend_after=sa)
-elif exp == "cheap2":
+elif exp == "planes":
     for sid in (1, 13):
         for kid in range(11):
             for sa in ((-1, -1), (128, 0), (192, 0), (256, 0)):
                 run(sid, kid, repeats=7, warmup=2, suspend_after=sa)
-elif exp == "cheap3":
+elif exp == "survey":
     for sid in (0, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 14, 15, 16, 17, 18, 19):
         for kid in (0, 5, 10, 9):
             for sa in ((-1, -1), (128, 0)):
@@ -133,16 +125,6 @@ elif exp == "refill":
     for sid, kid in ((0, 0), (2, 0), (9, 0), (12, 0), (13, 0), (1, 5), (7, 2), (16, 0), (19, 0), (5, 0)):
         for rm_ in (4, 8, 16, 24, 32, 48):
             run(sid, kid, repeats=9, warmup=2, refill_min=rm_)
-elif exp == "exp2":
-    for sid in (14, 15, 16, 19):
-        for kid in (0, 5):
-            for sa in ((-1, -1), (24, 0), (32, 0), (48, 0), (32, 128), (64, 0)):
-                run(sid, kid, repeats=5, warmup=2, suspend_after=sa)
-elif exp == "cheap4":
-    for sid in (0, 3, 5, 7, 8, 9, 12, 2, 4):
-        for kid in (0, 5):
-            for sa in ((-1, -1), (24, 0), (32, 0), (48, 0), (64, 0), (96, 0)):
-                run(sid, kid, repeats=7, warmup=2, suspend_after=sa)
 elif exp == "union":
     import numpy as np
     for sid in (14, 15):
@@ -158,36 +140,12 @@ elif exp == "union":
         for kid in (0, 5):
             for sa in ((-1, -1), (16, 0), (24, 0), (32, 0), (48, 0), (32, 128), (24, 96)):
                 run(sid, kid, repeats=5, warmup=2, suspend_after=sa)
-elif exp == "gyroid":
-    for kid in (0, 5, 10, 4):
-        for sa in ((-1, -1), (16, 0), (24, 0), (32, 0), (48, 0)):
-            for rm_ in (1, 2):
-                run(16, kid, repeats=5, warmup=2, suspend_after=sa, resume_mode=rm_)
 elif exp == "one":
     run(int(sys.argv[2]), int(sys.argv[3]), repeats=int(sys.argv[4]) if len(sys.argv) > 4 else 5)
 elif exp == "matrix":
     for sid in range(14):
         for key in registry.GRADED_STRATEGY_KEYS:
             run(sid, registry.STRATEGIES[key], repeats=3, warmup=1)
-elif exp == "lpt":
-    for sid, kid in ((10, 0), (10, 4), (12, 0), (13, 0), (0, 0)):
-        run(sid, kid, repeats=7, warmup=2)
-        run(sid, kid, repeats=7, warmup=2, tile_order_mode=1)
-    run(10, 0, W=3840, H=2160, repeats=3, warmup=1)
-    run(10, 0, W=3840, H=2160, repeats=3, warmup=2, tile_order_mode=1)
-elif exp == "lpt2":
-    for gw in (512, 1024, 1536, 2048):
-        run(10, 0, repeats=7, warmup=2, grid_waves=gw)
-        run(10, 0, repeats=7, warmup=2, grid_waves=gw, tile_order_mode=1)
-    for rm_ in (1, 4, 16):
-        run(10, 0, repeats=7, warmup=2, refill_min=rm_, tile_order_mode=1)
-elif exp == "lpt3":
-    for gw in (256, 384, 512, 640, 768, 1024, 2048):
-        run(10, 0, repeats=5, warmup=2, grid_waves=gw, tile_order_mode=1)
-elif exp == "center":
-    for sid, kid in ((10, 0), (10, 4), (12, 0), (0, 0), (13, 0)):
-        for gw in (512, 768, 1024, 2048):
-            run(sid, kid, repeats=7, warmup=2, grid_waves=gw, tile_order_mode=2)
 elif exp == "batch":
     import math, time
     import numpy as np
@@ -206,12 +164,3 @@ elif exp == "batch":
             seq = (time.perf_counter() - t0) * 1e3
             print(json.dumps(dict(scene=scene.name, frames=n, WxH=f"{w}x{h}", batch_ms=round(out["ms_total"], 3), per_frame_ms=round(out["ms_total"] / n, 3),
                                   mrays=round(n * w * h / out["ms_total"] / 1e3, 1), sequential_wall_ms=round(seq, 2))), flush=True)
-elif exp == "prio":
-    for _ in range(2):
-        run(10, 0, repeats=9, warmup=2)
-    run(10, 0, repeats=9, warmup=2, tile_order_mode=1)
-    run(10, 0, repeats=9, warmup=2, tile_order_mode=1, grid_waves=512)
-    run(10, 0, repeats=9, warmup=2, tile_order_mode=1, grid_waves=1024)
-    run(10, 4, repeats=9, warmup=2)
-    run(12, 0, repeats=9, warmup=2)
-    run(10, 0, W=3840, H=2160, repeats=3, warmup=1)
