@@ -158,6 +158,23 @@ int rm_march_rays_team(int scene_id, int strategy_id, const RmMarchConfig* cfg, 
 int rm_render(const RmFrameDesc* desc, float* depth, int32_t* iters, uint8_t* hit, double* t_raw,
               double* final_sdf, int64_t* block_var, RmStats* stats, RmTiming* timing);
 
+/* rm_render with the output pointers in a record, plus one more optional map:
+ *   evals   int32 per ray: the number of SDF evaluations its march performed -- what the reference's GLSL
+ *           backend counts in g_evals (gpu/shaders/scenes.glsl:10-12).  With march.full = 1 this is the number
+ *           of sdf() calls the reference's CPU march() makes for that ray (it also evaluates once more for
+ *           final_sdf on a miss and at bisection exits); with full = 0 those final_sdf-only evaluations are skipped.
+ * Iterations are not evaluations: Segment, RevAA and Hybrid evaluate more than once per counted iteration. */
+typedef struct RmOutputs {
+    float* depth;        /* required */
+    int32_t* iters;      /* required */
+    uint8_t* hit;        /* required */
+    double* t_raw;       /* optional, as rm_render */
+    double* final_sdf;
+    int64_t* block_var;
+    int32_t* evals;
+} RmOutputs;
+int rm_render_outputs(const RmFrameDesc* desc, const RmOutputs* out, RmStats* stats, RmTiming* timing);
+
 /* Same render, outputs left in device memory (caller-owned device pointers, e.g. torch
  * tensors handed to RCCL afterwards).  Asynchronous on `stream` (a hipStream_t, NULL = the
  * library stream).  d_stats: device buffer of rm_stats_device_bytes() bytes or NULL to use

@@ -19,7 +19,7 @@ Layout of each frames_*.npz (keys prefixed "s{scene_id}_k{strategy_id}_"):
   cam     float64 (14,)       position, forward, right, up, half_width, half_height
   meta    float64 (8,)        W, H, row0, rows, max_iterations, hit_threshold, max_distance, lipschitz
 
-Usage:  python oracle/gen_golden.py [--only frames64|frames160|rows1080|sdf|stats|leak|viewpoints]
+Usage:  python oracle/gen_golden.py [--only frames64|frames160|rows1080|sdf|stats|leak|viewpoints|evals]
 """
 from __future__ import annotations
 
@@ -171,6 +171,36 @@ def gen_sdf(n=2000):
     np.savez_compressed(os.path.join(OUT, "sdf_points.npz"), **store)
 
 
+def gen_evals(W=48, H=36, scene_ids=(0, 1, 9, 10, 12, 15)):
+    """SDF evaluations per ray: strategy.march is given a counting wrapper of scene.sdf, so the count is what
+    the reference's own march() calls (the quantity its GLSL backend exposes as g_evals, scenes.glsl:10-12).
+    All 11 strategies on a few scenes; iterations ride along to tie the two together."""
+    mc = MarchConfig()
+    store = {}
+    for sid in scene_ids:
+        for kid in range(len(STRAT_KEYS)):
+            scene, strategy, cam, lip, _ = wire(sid, kid, W, H)
+            calls = [0]
+
+            def counted(p, _sdf=scene.sdf, _c=calls):
+                _c[0] += 1
+                return _sdf(p)
+            evals, iters = [], []
+            for py in range(H):
+                for px in range(W):
+                    calls[0] = 0
+                    r = strategy.march(cam.get_ray(px, py), counted, mc)
+                    evals.append(calls[0])
+                    iters.append(r.iterations)
+            pre = f"s{sid}_k{kid}_"
+            store[pre + "evals"] = np.array(evals, dtype=np.int16).reshape(H, W)
+            store[pre + "iters"] = np.array(iters, dtype=np.int16).reshape(H, W)
+            store[pre + "cam"] = cam14(cam)
+            store[pre + "meta"] = np.array([W, H, 0, H, mc.max_iterations, mc.hit_threshold, mc.max_distance, lip], dtype=np.float64)
+            print(f"  [evals] {scene.name} / {strategy.short_name}: evals {sum(evals)} iterations {sum(iters)}", flush=True)
+    np.savez_compressed(os.path.join(OUT, f"evals_{W}x{H}.npz"), **store)
+
+
 def gen_viewpoints():
     """The reference's curated viewpoints (viewpoints.py:41-140) for every catalogue scene, as data."""
     from raymarching_benchmark.viewpoints import viewpoints_for
@@ -193,6 +223,8 @@ def main():
     graded9 = [0, 1, 2, 3, 4, 5, 6, 9, 10]  # the README's nine strategies (ids in STRATEGIES order)
     if a.only in ("all", "viewpoints"):
         gen_viewpoints()
+    if a.only in ("all", "evals"):
+        gen_evals()
     if a.only in ("all", "sdf"):
         gen_sdf()
     if a.only in ("all", "frames64"):

@@ -23,7 +23,7 @@ ERROR_NAMES = {0: "RM_OK", -1: "RM_E_BAD_SCENE", -2: "RM_E_BAD_STRATEGY", -3: "R
 
 EXPORTS = [
     "rm_init", "rm_shutdown", "rm_last_error", "rm_device_info", "rm_num_scenes", "rm_num_strategies",
-    "rm_sdf_eval", "rm_march_rays", "rm_march_rays_team", "rm_render", "rm_render_device", "rm_stats_device_bytes",
+    "rm_sdf_eval", "rm_march_rays", "rm_march_rays_team", "rm_render", "rm_render_outputs", "rm_render_device", "rm_stats_device_bytes",
     "rm_read_stats", "rm_bench_device", "rm_alloc_frame", "rm_free_frame", "rm_copy_frame_to_host",
     "rm_bench_store_path", "rm_render_batch", "rm_set_pass_timing", "rm_get_pass_ms", "rm_set_queue_capacity",
 ]
@@ -52,6 +52,12 @@ class RmFrameDesc(ctypes.Structure):
                 ("tile_order_mode", ctypes.c_int32), ("eval_mode", ctypes.c_int32),
                 ("suspend_after", ctypes.c_int32 * 2),
                 ("resume_grid", ctypes.c_int32), ("resume_mode", ctypes.c_int32)]
+
+
+class RmOutputs(ctypes.Structure):
+    _fields_ = [("depth", ctypes.c_void_p), ("iters", ctypes.c_void_p), ("hit", ctypes.c_void_p),
+                ("t_raw", ctypes.c_void_p), ("final_sdf", ctypes.c_void_p), ("block_var", ctypes.c_void_p),
+                ("evals", ctypes.c_void_p)]
 
 
 class RmStats(ctypes.Structure):
@@ -100,6 +106,8 @@ def load() -> ctypes.CDLL:
         L.rm_march_rays_team.argtypes = L.rm_march_rays.argtypes
         L.rm_render.argtypes = [ctypes.POINTER(RmFrameDesc), vp, vp, vp, vp, vp, vp,
                                 ctypes.POINTER(RmStats), ctypes.POINTER(RmTiming)]
+        L.rm_render_outputs.argtypes = [ctypes.POINTER(RmFrameDesc), ctypes.POINTER(RmOutputs), ctypes.POINTER(RmStats),
+                                        ctypes.POINTER(RmTiming)]
         L.rm_render_device.argtypes = [ctypes.POINTER(RmFrameDesc), vp, vp, vp, vp, vp]
         L.rm_stats_device_bytes.restype = ctypes.c_size_t
         L.rm_read_stats.argtypes = [vp, vp, ctypes.POINTER(RmStats)]
@@ -198,13 +206,15 @@ def stats_dict(s: RmStats) -> dict:
 
 
 def render(desc: RmFrameDesc, want_t_raw=False, want_final_sdf=False, want_block_var=False, warmup=0,
-           repeats=0) -> dict:
-    """rm_render into fresh NumPy arrays.  Returns depth (f32), iters (i32), hit (u8), optional
-    t_raw / final_sdf (f64) / block_var (i64), stats (dict) and timing (dict or None)."""
+           repeats=0, want_evals=False) -> dict:
+    """rm_render_outputs into fresh NumPy arrays.  Returns depth (f32), iters (i32), hit (u8), optional
+    t_raw / final_sdf (f64) / block_var (i64) / evals (i32), stats (dict) and timing (dict or None)."""
     L = init()
     rows, W = desc.rows, desc.width
     out = {"depth": np.empty((rows, W), np.float32), "iters": np.empty((rows, W), np.int32),
-           "hit": np.empty((rows, W), np.uint8), "t_raw": None, "final_sdf": None, "block_var": None}
+           "hit": np.empty((rows, W), np.uint8), "t_raw": None, "final_sdf": None, "block_var": None, "evals": None}
+    if want_evals:
+        out["evals"] = np.empty((rows, W), np.int32)
     if want_t_raw:
         out["t_raw"] = np.empty((rows, W), np.float64)
     if want_final_sdf:
@@ -216,9 +226,12 @@ def render(desc: RmFrameDesc, want_t_raw=False, want_final_sdf=False, want_block
     if repeats > 0:
         tm = RmTiming()
         tm.warmup, tm.repeats = int(warmup), int(repeats)
-    check(L.rm_render(ctypes.byref(desc), _ptr(out["depth"]), _ptr(out["iters"]), _ptr(out["hit"]),
-                      _ptr(out["t_raw"]), _ptr(out["final_sdf"]), _ptr(out["block_var"]), ctypes.byref(st),
-                      ctypes.byref(tm) if tm is not None else None))
+    def addr(a):
+        return None if a is None else a.ctypes.data
+    o = RmOutputs(addr(out["depth"]), addr(out["iters"]), addr(out["hit"]), addr(out["t_raw"]), addr(out["final_sdf"]),
+                  addr(out["block_var"]), addr(out["evals"]))
+    check(L.rm_render_outputs(ctypes.byref(desc), ctypes.byref(o), ctypes.byref(st),
+                              ctypes.byref(tm) if tm is not None else None))
     out["stats"] = stats_dict(st)
     out["timing"] = timing_dict(tm) if tm is not None else None
     return out

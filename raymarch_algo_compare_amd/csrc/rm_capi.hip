@@ -78,7 +78,7 @@ struct State {
     int device = -1;
     hipStream_t stream = nullptr;
     hipDeviceProp_t prop;
-    Buf stats, depth, iters, hit, traw, fs, bvar, in0, in1, out0, out1, out2, out3, tcost, torder, queue[rm::kQueues];
+    Buf stats, depth, iters, hit, traw, fs, bvar, evals, in0, in1, out0, out1, out2, out3, tcost, torder, queue[rm::kQueues];
     // shape of the frame whose per-tile costs sit in `tcost` (tile_order_mode 1 needs a match)
     long long cost_key[10] = { -1 };
     bool cost_valid = false;
@@ -523,7 +523,7 @@ void rm_shutdown(void)
     if (!g.ready) return;
     (void)hipSetDevice(g.device);
     (void)hipStreamSynchronize(g.stream);
-    for (Buf* b : { &g.bstats, &g.stats, &g.depth, &g.iters, &g.hit, &g.traw, &g.fs, &g.bvar, &g.in0, &g.in1, &g.out0, &g.out1,
+    for (Buf* b : { &g.bstats, &g.stats, &g.depth, &g.iters, &g.hit, &g.traw, &g.fs, &g.bvar, &g.evals, &g.in0, &g.in1, &g.out0, &g.out1,
                     &g.out2, &g.out3, &g.tcost, &g.torder, &g.queue[0], &g.queue[1] })
         b->release();
     if (g.events) for (auto& e : g.ev) (void)hipEventDestroy(e);
@@ -616,47 +616,58 @@ int rm_march_rays_team(int scene_id, int strategy_id, const RmMarchConfig* cfg, 
     return march_rays_impl(true, scene_id, strategy_id, cfg, origins, dirs, n, hit, t, iters, final_sdf);
 }
 
-int rm_render(const RmFrameDesc* d, float* depth, int32_t* iters, uint8_t* hit, double* t_raw, double* final_sdf,
-              int64_t* block_var, RmStats* stats, RmTiming* timing)
+int rm_render_outputs(const RmFrameDesc* d, const RmOutputs* o, RmStats* stats, RmTiming* timing)
 {
     int rc = check_ready();
     if (rc) return rc;
     if ((rc = check_desc(d))) return rc;
-    if (!depth || !iters || !hit) return fail(RM_E_BAD_ARG, "depth, iters and hit are required");
-    if (final_sdf && !d->march.full) return fail(RM_E_BAD_ARG, "final_sdf requires march.full = 1");
-    if (block_var && (d->row0 % 4) != 0) return fail(RM_E_BAD_ARG, "block_var requires row0 %% 4 == 0");
+    if (!o || !o->depth || !o->iters || !o->hit) return fail(RM_E_BAD_ARG, "depth, iters and hit are required");
+    if (o->final_sdf && !d->march.full) return fail(RM_E_BAD_ARG, "final_sdf requires march.full = 1");
+    if (o->block_var && (d->row0 % 4) != 0) return fail(RM_E_BAD_ARG, "block_var requires row0 %% 4 == 0");
     std::lock_guard<std::mutex> lk(g_mu);
     HIP_TRY(hipSetDevice(g.device));
     const size_t n = (size_t)d->rows * (size_t)d->width;
     const size_t nblk = (size_t)(d->rows / 4) * (size_t)(d->width / 8);
     if ((rc = g.depth.ensure(n * 4 + 16)) || (rc = g.iters.ensure(n * 4 + 16)) || (rc = g.hit.ensure(n + 16))) return rc;
-    if (t_raw && (rc = g.traw.ensure(n * 8 + 16))) return rc;
-    if (final_sdf && (rc = g.fs.ensure(n * 8 + 16))) return rc;
-    if (block_var && (rc = g.bvar.ensure(nblk * 8 + 16))) return rc;
+    if (o->t_raw && (rc = g.traw.ensure(n * 8 + 16))) return rc;
+    if (o->final_sdf && (rc = g.fs.ensure(n * 8 + 16))) return rc;
+    if (o->block_var && (rc = g.bvar.ensure(nblk * 8 + 16))) return rc;
+    if (o->evals && (rc = g.evals.ensure(n * 4 + 16))) return rc;
     rm::KernelArgs a;
     int tile_h = 0, grid = 0;
-    if ((rc = make_args(d, (float*)g.depth.p, (int32_t*)g.iters.p, (uint8_t*)g.hit.p, t_raw ? (double*)g.traw.p : nullptr,
-                        final_sdf ? (double*)g.fs.p : nullptr, block_var ? (long long*)g.bvar.p : nullptr,
+    if ((rc = make_args(d, (float*)g.depth.p, (int32_t*)g.iters.p, (uint8_t*)g.hit.p, o->t_raw ? (double*)g.traw.p : nullptr,
+                        o->final_sdf ? (double*)g.fs.p : nullptr, o->block_var ? (long long*)g.bvar.p : nullptr,
                         (unsigned long long*)g.stats.p, &a, &tile_h, &grid)))
         return rc;
+    a.evals = o->evals ? (int32_t*)g.evals.p : nullptr;
     if (timing) {
         if ((rc = timed_launches(d, a, tile_h, grid, timing))) return rc;
     } else {
         if ((rc = launch(d, a, tile_h, grid, g.stream))) return rc;
     }
     if (n) {
-        HIP_TRY(hipMemcpyAsync(depth, g.depth.p, n * 4, hipMemcpyDeviceToHost, g.stream));
-        HIP_TRY(hipMemcpyAsync(iters, g.iters.p, n * 4, hipMemcpyDeviceToHost, g.stream));
-        HIP_TRY(hipMemcpyAsync(hit, g.hit.p, n, hipMemcpyDeviceToHost, g.stream));
-        if (t_raw) HIP_TRY(hipMemcpyAsync(t_raw, g.traw.p, n * 8, hipMemcpyDeviceToHost, g.stream));
-        if (final_sdf) HIP_TRY(hipMemcpyAsync(final_sdf, g.fs.p, n * 8, hipMemcpyDeviceToHost, g.stream));
-        if (block_var && nblk) HIP_TRY(hipMemcpyAsync(block_var, g.bvar.p, nblk * 8, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipMemcpyAsync(o->depth, g.depth.p, n * 4, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipMemcpyAsync(o->iters, g.iters.p, n * 4, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipMemcpyAsync(o->hit, g.hit.p, n, hipMemcpyDeviceToHost, g.stream));
+        if (o->t_raw) HIP_TRY(hipMemcpyAsync(o->t_raw, g.traw.p, n * 8, hipMemcpyDeviceToHost, g.stream));
+        if (o->final_sdf) HIP_TRY(hipMemcpyAsync(o->final_sdf, g.fs.p, n * 8, hipMemcpyDeviceToHost, g.stream));
+        if (o->block_var && nblk) HIP_TRY(hipMemcpyAsync(o->block_var, g.bvar.p, nblk * 8, hipMemcpyDeviceToHost, g.stream));
+        if (o->evals) HIP_TRY(hipMemcpyAsync(o->evals, g.evals.p, n * 4, hipMemcpyDeviceToHost, g.stream));
     }
     unsigned long long w[rm::kStatsWords];
     HIP_TRY(hipMemcpyAsync(w, g.stats.p, kStatsBlockBytes, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
     if (stats) decode_stats(w, stats);
     return RM_OK;
+}
+
+int rm_render(const RmFrameDesc* d, float* depth, int32_t* iters, uint8_t* hit, double* t_raw, double* final_sdf,
+              int64_t* block_var, RmStats* stats, RmTiming* timing)
+{
+    RmOutputs o;
+    memset(&o, 0, sizeof o);
+    o.depth = depth; o.iters = iters; o.hit = hit; o.t_raw = t_raw; o.final_sdf = final_sdf; o.block_var = block_var;
+    return rm_render_outputs(d, &o, stats, timing);
 }
 
 int rm_render_device(const RmFrameDesc* d, void* d_depth, void* d_iters, void* d_hit, void* d_stats, void* stream)

@@ -87,6 +87,8 @@ struct KernelArgs {
     int32_t* iters;           // rows*width
     uint8_t* hit;             // rows*width
     double* t_raw;            // optional: raw fp64 t of every ray (parity tests)
+    int32_t* evals;           // optional: SDF evaluations the march of every ray performed (needs cfg.full for the
+                              // reference's count: its march() also evaluates for final_sdf)
     double* final_sdf;        // optional: MarchResult.final_sdf (needs cfg.full)
     long long* block_var;     // optional: (rows/4) x (width/8) variance numerators 32*sum(x^2)-sum(x)^2
     unsigned long long* stats;
@@ -107,10 +109,11 @@ __device__ __forceinline__ int rank_in_mask(unsigned long long m)
 
 // t_raw / final_sdf are parity-test outputs (fp64, every ray): written straight to global
 // memory when requested, never staged (they are not part of the 9 B/ray product path).
-__device__ __forceinline__ void store_raw(const KernelArgs& a, uint32_t gi, const Result& r)
+__device__ __forceinline__ void store_raw(const KernelArgs& a, uint32_t gi, const Result& r, int nev)
 {
     if (a.t_raw) a.t_raw[gi] = r.t;
     if (a.final_sdf) a.final_sdf[gi] = r.final_sdf;
+    if (a.evals) a.evals[gi] = nev;
 }
 
 constexpr int kWavesPerWG = 4;         // 256-thread workgroups: four waves share one LDS copy of the libm tables
@@ -160,14 +163,14 @@ constexpr uint32_t kSuspended = 0xffffffffu;   // staging mark of a pixel whose 
 template <class Strat>
 struct QEntry {
     uint32_t gi;
-    uint32_t pad;
+    uint32_t nev;   // SDF evaluations performed so far (KernelArgs.evals)
     Strat s;
 };
 
 // Wave-uniform call: lanes with `want` append their ray to queue q (one atomic per wave).  Returns
 // per lane whether the ray was parked; a full queue leaves the ray where it is.
 template <class Strat>
-__device__ __forceinline__ bool push_suspended(const KernelArgs& a, int q, bool want, uint32_t gi, const Strat& s)
+__device__ __forceinline__ bool push_suspended(const KernelArgs& a, int q, bool want, uint32_t gi, const Strat& s, int nev)
 {
     const unsigned long long m = __ballot(want);
     if (m == 0) return false;
@@ -179,7 +182,7 @@ __device__ __forceinline__ bool push_suspended(const KernelArgs& a, int q, bool 
     if (ok) {
         QEntry<Strat>* e = (QEntry<Strat>*)a.queue[q] + idx;
         e->gi = gi;
-        e->pad = 0;
+        e->nev = (uint32_t)nev;
         e->s = s;
     }
     return ok;
@@ -289,6 +292,7 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
     bool active = false;
     int my_slot = 0, my_pix = 0;                  // where its result goes: slot, tile-linear index y*64+x
     uint32_t my_gi = 0;                           // ... and its element index in the output arrays
+    int nev = 0;                                  // SDF evaluations this ray's march has performed
     vec3 origin = v3(0.0, 0.0, 0.0), dir = v3(0.0, 0.0, 0.0);
     MarchCfg cfg;                                 // of the frame this lane's ray belongs to
     cfg.hit_threshold = 0.0; cfg.max_distance = 0.0; cfg.lipschitz = 1.0; cfg.max_iterations = 0; cfg.full = a.full;
@@ -419,10 +423,11 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
                         cfg.max_distance = fp.cfg.max_distance;
                         cfg.lipschitz = fp.cfg.lipschitz;
                         cfg.max_iterations = fp.cfg.max_iterations;
+                        nev = 0;
                         if (s.start(cfg)) {
                             s_depth[cur][my_pix] = s.res.hit ? (float)s.res.t : 0.0f;
                             s_ih[cur][my_pix] = (uint32_t)s.res.iters | ((uint32_t)s.res.hit << 31);
-                            store_raw(a, my_gi, s.res);
+                            store_raw(a, my_gi, s.res, nev);
                         } else {
                             active = true;
                             started = true;
@@ -460,12 +465,13 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
             double d;
             if constexpr (INTERLEAVE) d = Scene::value(ev);
             else d = Scene::sdf(origin + dir * s.te);   // ray.py:15-17
+            ++nev;
             if (s.step(d, cfg)) {
                 active = false;
                 fin = true;
                 s_depth[my_slot][my_pix] = s.res.hit ? (float)s.res.t : 0.0f;   // types.py:93
                 s_ih[my_slot][my_pix] = (uint32_t)s.res.iters | ((uint32_t)s.res.hit << 31);
-                store_raw(a, my_gi, s.res);
+                store_raw(a, my_gi, s.res, nev);
             } else if (a.suspend_after > 0 && s.i >= a.suspend_after) {
                 park = true;
             } else if constexpr (INTERLEAVE) {
@@ -474,7 +480,7 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
         }
         if (a.suspend_after > 0 && __any(park)) {
             // long rays leave the wave: their lanes take fresh pixels, resume_kernel finishes them
-            const bool parked = push_suspended(a, a.suspend_queue, park, my_gi, s);
+            const bool parked = push_suspended(a, a.suspend_queue, park, my_gi, s, nev);
             if (parked) {
                 s_ih[my_slot][my_pix] = kSuspended;
                 active = false;
@@ -537,6 +543,7 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void resume_kernel(const KernelAr
     bool more = count > 0;
     bool active = false;
     uint32_t my_gi = 0;
+    int nev = 0;
     vec3 origin = v3(0.0, 0.0, 0.0), dir = v3(0.0, 0.0, 0.0);
     MarchCfg cfg;
     cfg.hit_threshold = 0.0; cfg.max_distance = 0.0; cfg.lipschitz = 1.0; cfg.max_iterations = 0; cfg.full = a.full;
@@ -562,6 +569,7 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void resume_kernel(const KernelAr
                     const Entry e = queue[idx];
                     my_gi = e.gi;
                     s = e.s;
+                    nev = (int)e.nev;
                     const uint32_t frame = my_gi / frame_elems;
                     const uint32_t pix = my_gi - frame * frame_elems;
                     const int y = (int)(pix / (uint32_t)a.width);
@@ -595,13 +603,14 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void resume_kernel(const KernelAr
                 double d;
                 if constexpr (INTERLEAVE) d = Scene::value(ev);
                 else d = Scene::sdf(origin + dir * s.te);   // ray.py:15-17
-                if (s.step(d, cfg)) {
+                ++nev;
+            if (s.step(d, cfg)) {
                     active = false;
                     const int it = s.res.iters, h = s.res.hit;
                     a.depth[my_gi] = h ? (float)s.res.t : 0.0f;   // types.py:93
                     a.iters[my_gi] = it;
                     a.hit[my_gi] = (uint8_t)h;
-                    store_raw(a, my_gi, s.res);
+                    store_raw(a, my_gi, s.res, nev);
                     acc.add(it, h);
                     atomicAdd(&s_hist[min(it, a.hist_bins - 1)], 1u);
                     if (a.tile_cost) {
@@ -617,7 +626,7 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void resume_kernel(const KernelAr
                 }
             }
             if (a.suspend_after > 0 && __any(park)) {
-                const bool parked = push_suspended(a, a.suspend_queue, park, my_gi, s);
+                const bool parked = push_suspended(a, a.suspend_queue, park, my_gi, s, nev);
                 if (parked) {
                     active = false;
                 } else if (park) {
@@ -759,6 +768,7 @@ __global__ __launch_bounds__(64 * kTeam) void resume_team_kernel(const KernelArg
     bool more = count > 0;
     bool active = false;
     uint32_t my_gi = 0;
+    int nev = 0;
     vec3 origin = v3(0.0, 0.0, 0.0), dir = v3(0.0, 0.0, 0.0);
     MarchCfg cfg;
     cfg.hit_threshold = 0.0; cfg.max_distance = 0.0; cfg.lipschitz = 1.0; cfg.max_iterations = 0; cfg.full = a.full;
@@ -782,6 +792,7 @@ __global__ __launch_bounds__(64 * kTeam) void resume_team_kernel(const KernelArg
                     const Entry e = queue[idx];
                     my_gi = e.gi;
                     s = e.s;
+                    nev = (int)e.nev;
                     const uint32_t frame = my_gi / frame_elems;
                     const uint32_t pix = my_gi - frame * frame_elems;
                     const int y = (int)(pix / (uint32_t)a.width);
@@ -814,6 +825,7 @@ __global__ __launch_bounds__(64 * kTeam) void resume_team_kernel(const KernelArg
         }
         bool park = false;
         if (active) {
+            ++nev;
             if (!s.step(Scene::value(ev), cfg)) {
                 park = a.suspend_after > 0 && s.i >= a.suspend_after;
             } else {
@@ -823,7 +835,7 @@ __global__ __launch_bounds__(64 * kTeam) void resume_team_kernel(const KernelArg
                 a.depth[my_gi] = h ? (float)s.res.t : 0.0f;   // types.py:93
                 a.iters[my_gi] = it;
                 a.hit[my_gi] = (uint8_t)h;
-                store_raw(a, my_gi, s.res);
+                store_raw(a, my_gi, s.res, nev);
                 acc.add(it, h);
                 atomicAdd(&s_hist[min(it, a.hist_bins - 1)], 1u);
                 if (a.tile_cost) {
@@ -847,7 +859,7 @@ __global__ __launch_bounds__(64 * kTeam) void resume_team_kernel(const KernelArg
                 if (part == 0) {
                     Entry* e = (Entry*)a.queue[a.suspend_queue] + idx;
                     e->gi = my_gi;
-                    e->pad = 0;
+                    e->nev = (uint32_t)nev;
                     e->s = s;
                 }
                 active = false;

@@ -120,3 +120,29 @@ def test_block_var_matches_reference_proxy(hip):
         want = G.stats[f"s{sid}_k{kid}"]["warp_divergence_proxy"]
         assert warp_divergence_from_block_var(out["block_var"]) == want
         assert warp_divergence_proxy(out["iters"]) == want
+
+
+def test_evaluation_counts_match_the_reference(hip):
+    """RmOutputs.evals: SDF evaluations per ray.  tests/golden/evals_48x36.npz holds the number of scene.sdf
+    calls the reference's own march() made for every ray (oracle/gen_golden.py wraps sdf in a counter) for all 11
+    strategies on six scenes; with march.full = 1 the kernels perform exactly those evaluations -- under every
+    schedule, since a parked ray carries its count."""
+    import os
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "evals_48x36.npz"))
+    pairs = sorted({tuple(int(p[1:]) for p in k.split("_")[:2]) for k in z.files})
+    assert len(pairs) == 66
+    for sid, kid in pairs:
+        pre = f"s{sid}_k{kid}_"
+        m = z[pre + "meta"]
+        W, H = int(m[0]), int(m[1])
+        for sched in (dict(suspend_after=(-1, -1)), dict(suspend_after=(3, 11), resume_mode=2), dict(suspend_after=(4, 0), resume_mode=1)):
+            desc = hip.make_desc(sid, kid, z[pre + "cam"], W, H, 0, H, int(m[4]), float(m[5]), float(m[6]), float(m[7]), True, **sched)
+            out = hip.render(desc, want_evals=True)
+            assert (out["iters"] == z[pre + "iters"]).all(), (sid, kid, sched)
+            assert (out["evals"] == z[pre + "evals"]).all(), (sid, kid, sched, int((out["evals"] != z[pre + "evals"]).sum()))
+    # without full the final_sdf-only evaluations are skipped: never more evaluations, same iterations
+    pre = "s10_k6_"
+    m = z[pre + "meta"]
+    lean = hip.render(hip.make_desc(10, 6, z[pre + "cam"], 48, 36, 0, 36, int(m[4]), float(m[5]), float(m[6]), float(m[7]), False), want_evals=True)
+    assert (lean["evals"] <= z[pre + "evals"]).all() and (lean["evals"] < z[pre + "evals"]).any() and (lean["iters"] == z[pre + "iters"]).all()
