@@ -57,3 +57,112 @@ def run_gpu_benchmark(scene_name: str, strategy_name: str, render_cfg: RenderCon
         # exact integer maps for consumers that do not want the float32 round trip
         "iterations": out["iters"], "hit": out["hit"], "depth": out["depth"],
     }
+
+
+# ---- GPURunner: the reference's runner object (gpu/runner.py:17-268) on the gfx950 engine -------------------
+
+# strategy ids of the reference's fragment shader (main.glsl:64-74) -> registry keys of this engine
+GLSL_STRATEGY_KEYS = {0: "Standard", 1: "Overstep-Bisect", 2: "Relaxed", 3: "Segment", 4: "Enhanced",
+                      5: "Heuristic-Auto-Relaxed", 6: "Skipping-Spheres", 7: "RevAA"}
+# uniforms the shader takes per run (runner.py:112-127) and the values the CPU-path strategies are built with
+_PARAM_DEFAULTS = {"omega": 1.2, "kappa": 2.0, "beta": 0.3, "margin": 0.05, "stepScale": 1.0}
+
+
+class GPURunner:
+    """`GPURunner.render` / `GPURunner.capture` with the reference's signatures and result layouts
+    (gpu/runner.py:58-166, :168-268), evaluated by the gfx950 kernels with the CPU path's arithmetic.
+
+    Deliberate differences: fp64 and the CPU camera model (the shader's pinhole ignores
+    fov), the catalogue SDFs, rows top-to-bottom in both calls, `strategy_id` follows the shader's numbering
+    (GLSL_STRATEGY_KEYS; 8 = Safe-Relaxed and 9 = Dense-March exist only in GLSL and raise ValueError; pass
+    `strategy_key=` for this engine's other strategies), and `params` may only restate the defaults -- the
+    strategies' tuning constants are compiled in, as the registry builds them (`minStep` is GLSL-only, ignored)."""
+
+    def __init__(self, device_id: int | None = None):
+        self.device_id = device_id
+
+    @staticmethod
+    def _strategy(strategy_id, strategy_key):
+        if strategy_key is None:
+            if strategy_id not in GLSL_STRATEGY_KEYS:
+                raise ValueError(f"strategy id {strategy_id} has no CPU-path counterpart (GLSL-only)")
+            strategy_key = GLSL_STRATEGY_KEYS[strategy_id]
+        st = get_strategy_by_name(strategy_key)
+        if st is None:
+            raise KeyError(f"unknown strategy {strategy_key!r}")
+        return st
+
+    @staticmethod
+    def _check_params(params):
+        for k, v in (params or {}).items():
+            if k == "minStep":
+                continue
+            if k not in _PARAM_DEFAULTS:
+                raise KeyError(f"unknown shader parameter {k!r}")
+            if float(v) != _PARAM_DEFAULTS[k]:
+                raise NotImplementedError(f"{k}={v}: the strategies' constants are compiled in ({k}={_PARAM_DEFAULTS[k]})")
+
+    def _frame(self, scene_id, strategy, render_cfg, march_cfg, lipschitz, timed, want_evals):
+        if not 0 <= int(scene_id) < len(SCENES):
+            raise ValueError(f"scene id {scene_id} out of range")
+        cam = Camera(render_cfg.camera_position, render_cfg.camera_target, render_cfg.camera_up,
+                     render_cfg.fov_degrees, render_cfg.width, render_cfg.height)
+        _native.init(self.device_id)
+        lip = float(lipschitz if lipschitz is not None else 1.0) if strategy.has_lipschitz else 1.0
+        desc = _native.make_desc(int(scene_id), strategy.id, cam.params14(), cam.width, cam.height, 0, None,
+                                 march_cfg.max_iterations, march_cfg.hit_threshold, march_cfg.max_distance, lip, True)
+        out = _native.render(desc, want_t_raw=True, want_final_sdf=True, repeats=1 if timed else 0, want_evals=want_evals)
+        return cam, out
+
+    @staticmethod
+    def _geom(out, march_cfg):
+        h, w = out["iters"].shape
+        px = np.empty((h, w, 4), dtype=np.float32)                      # main.glsl:79-84
+        px[..., 0] = out["hit"]
+        px[..., 1] = out["iters"] / float(march_cfg.max_iterations)
+        px[..., 2] = out["t_raw"] / float(march_cfg.max_distance)
+        px[..., 3] = out["final_sdf"]
+        return px
+
+    def render(self, scene_id: int, strategy_id: int, render_cfg: RenderConfig, march_cfg: MarchConfig,
+               lipschitz: float = 1.0, params: dict | None = None, *, strategy_key: str | None = None):
+        """-> (pixels (H, W, 4) float32 [hit, iterations / max, t / max_distance, final_sdf], seconds)."""
+        self._check_params(params)
+        _, out = self._frame(scene_id, self._strategy(strategy_id, strategy_key), render_cfg, march_cfg, lipschitz, True, False)
+        return self._geom(out, march_cfg), out["timing"]["ms_median"] * 1e-3
+
+    def capture(self, scene_id: int, strategy_id: int, render_cfg: RenderConfig, march_cfg: MarchConfig,
+                lipschitz: float = 1.0, params: dict | None = None, *, strategy_key: str | None = None) -> dict:
+        """-> geom (H,W,4), normal (H,W,3), depth (H,W), color (H,W,3), evals (H,W), hit (H,W) bool -- the capture
+        targets of main.glsl:79-110: tetrahedron normals from four SDF evaluations (rm_sdf_eval) at the hit point,
+        the shader's fixed key light + hemisphere ambient + gamma, its background on misses, and the number of SDF
+        evaluations the march itself performed."""
+        self._check_params(params)
+        cam, out = self._frame(scene_id, self._strategy(strategy_id, strategy_key), render_cfg, march_cfg, lipschitz, False, True)
+        h, w = out["iters"].shape
+        hit = out["hit"] > 0
+        c = cam.params14()
+        u = (2.0 * (np.arange(w) + 0.5) / w - 1.0) * c[12]                   # camera.py:37-38
+        v = (1.0 - 2.0 * (np.arange(h) + 0.5) / h) * c[13]
+        rd = c[3:6][None, None, :] + c[6:9][None, None, :] * u[None, :, None] + c[9:12][None, None, :] * v[:, None, None]
+        rd /= np.sqrt((rd * rd).sum(2, keepdims=True))
+        depth = np.where(hit, out["t_raw"], 0.0)
+        normal = np.zeros((h, w, 3))
+        color = np.empty((h, w, 3))
+        tb = 0.5 * (rd[..., 1] + 1.0)                                          # main.glsl background()
+        color[:] = (1.0 - tb)[..., None] * np.array([0.06, 0.07, 0.09]) + tb[..., None] * np.array([0.12, 0.14, 0.18])
+        if hit.any():
+            pos = c[0:3][None, :] + depth[hit][:, None] * rd[hit]
+            e = 0.0005                                                         # calcNormal, main.glsl:26-35
+            ks = np.array([[1.0, -1.0, -1.0], [-1.0, -1.0, 1.0], [-1.0, 1.0, -1.0], [1.0, 1.0, 1.0]])
+            d4 = _native.sdf_eval(int(scene_id), (pos[:, None, :] + e * ks[None, :, :]).reshape(-1, 3)).reshape(-1, 4)
+            n = (d4[:, :, None] * ks[None, :, :]).sum(1)
+            n /= np.maximum(np.sqrt((n * n).sum(1, keepdims=True)), 1e-300)
+            normal[hit] = n
+            L = np.array([0.6, 0.7, 0.5]) / np.sqrt(0.6 ** 2 + 0.7 ** 2 + 0.5 ** 2)   # shade(), main.glsl:40-47
+            diff = np.maximum(n @ L, 0.0)
+            hemi = 0.5 + 0.5 * n[:, 1]
+            col = np.array([0.82, 0.80, 0.78])[None, :] * (0.15 * hemi + 0.85 * diff)[:, None]
+            color[hit] = np.clip(col, 0.0, 1.0) ** 0.4545
+        return {"geom": self._geom(out, march_cfg), "normal": normal.astype(np.float32), "depth": depth.astype(np.float32),
+                "color": color.astype(np.float32), "evals": out["evals"].astype(np.float32), "hit": hit}
