@@ -255,6 +255,7 @@ def main():
             "scaling": "strong" if wl["sharded"] else "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "mean_iters_per_ray": iters_step / max(rays_step, 1.0),
+            "mean_sdf_evals_per_ray": float(st.sum_evals) / max(float(st.total_rays), 1.0),
             "config": {"workload": f"{scene.name}/{wl['strategy']} {W}x{H}, MarchConfig(512, 1e-4, 100.0), "
                                    f"camera {scene.camera_position or (0.0, 0.0, 5.0)}",
                        "frames_per_step": 1 if wl["sharded"] else world,

@@ -101,6 +101,7 @@ typedef struct RmStats {
     int32_t iter_max;
     int32_t iter_min;
     uint64_t iter_hist[RM_HIST_BINS];
+    uint64_t sum_evals; /* SDF evaluations of all rays (see RmOutputs.evals; 0 in rm_render_batch's per-frame stats) */
 } RmStats;
 
 /* in: warmup, repeats (<= RM_MAX_TIMED).  out: per-launch kernel milliseconds measured with

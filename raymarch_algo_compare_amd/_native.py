@@ -63,7 +63,7 @@ class RmOutputs(ctypes.Structure):
 class RmStats(ctypes.Structure):
     _fields_ = [("total_rays", ctypes.c_uint64), ("hit_count", ctypes.c_uint64),
                 ("sum_iters", ctypes.c_uint64), ("iter_max", ctypes.c_int32), ("iter_min", ctypes.c_int32),
-                ("iter_hist", ctypes.c_uint64 * RM_HIST_BINS)]
+                ("iter_hist", ctypes.c_uint64 * RM_HIST_BINS), ("sum_evals", ctypes.c_uint64)]
 
 
 class RmTiming(ctypes.Structure):
@@ -201,7 +201,7 @@ def timing_dict(t: RmTiming) -> dict:
 
 def stats_dict(s: RmStats) -> dict:
     return {"total_rays": int(s.total_rays), "hit_count": int(s.hit_count), "sum_iters": int(s.sum_iters),
-            "iter_max": int(s.iter_max), "iter_min": int(s.iter_min),
+            "iter_max": int(s.iter_max), "iter_min": int(s.iter_min), "sum_evals": int(s.sum_evals),
             "iter_hist": np.ctypeslib.as_array(s.iter_hist).astype(np.int64).copy()}
 
 

@@ -254,7 +254,7 @@ __global__ void block_var_kernel(const int32_t* __restrict__ iters, int width, i
 __global__ void stats_reduce_kernel(unsigned long long* __restrict__ stats)
 {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;      // word index within a block
-    if (w >= rm::kStatsWords || w == 0 || (w >= 6 && w < rm::kStatsHead)) return;   // counters live in block 0 only
+    if (w >= rm::kStatsWords || w == 0 || (w >= 6 && w < 10) || (w > 10 && w < rm::kStatsHead)) return;   // counters live in block 0 only
     unsigned long long acc = 0;
     const bool is_max = (w == 3 || w == 4);
     for (int p = 1; p <= rm::kStatsParts; ++p) {
@@ -412,6 +412,7 @@ void decode_stats(const unsigned long long* w, RmStats* out)
     out->sum_iters = w[2];
     out->iter_max = (int32_t)w[3];
     out->total_rays = w[5];
+    out->sum_evals = w[10];
     out->iter_min = w[5] ? (int32_t)(0x7fffffffull - w[4]) : 0;
     for (int b = 0; b < RM_HIST_BINS; ++b) out->iter_hist[b] = w[rm::kStatsHead + b];
 }

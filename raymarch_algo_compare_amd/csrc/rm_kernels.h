@@ -60,9 +60,10 @@ constexpr int kStatsBlocks = 1 + kStatsParts;
 // device-side stats block (u64 words):
 //  [0] tile counter   [1] hit_count   [2] sum_iters   [3] iter_max   [4] 0x7fffffff - iter_min
 //  [5] rays written   [6..7] entries pushed to suspended-ray queue 0 / 1   [8..9] entries handed out
-//  of queue 0 / 1   [10..15] reserved   [16 .. 16+kHistBins) histogram of iterations
+//  of queue 0 / 1   [10] SDF evaluations of the finished rays   [11..15] reserved
+//  [16 .. 16+kHistBins) histogram of iterations
 // Block 0 holds the counters ([0], [6..9]) and, after stats_reduce_kernel, the totals; blocks 1..kStatsParts
-// hold the partial sums of words [1..5] and of the histogram.
+// hold the partial sums of words [1..5], [10] and of the histogram.
 // One frame of a launch: its camera and march configuration.  A launch renders `nframes` frames of the
 // same shape (1 for rm_render; rm_render_batch renders a whole viewpoint / budget sweep in one launch);
 // tile ids run frame-major, the output arrays are frame-major too.
@@ -196,7 +197,7 @@ __device__ __forceinline__ unsigned long long* stats_part(unsigned long long* st
 
 // Per-wave frame totals kept in registers; one atomic each at kernel exit.
 struct WaveAcc {
-    unsigned long long hits = 0, iters = 0, rays = 0;
+    unsigned long long hits = 0, iters = 0, rays = 0, evals = 0;
     int mx = 0, mn = 0x7fffffff;
     __device__ __forceinline__ void add(int it, int h)
     {
@@ -209,6 +210,7 @@ struct WaveAcc {
             hits += __shfl_xor(hits, off);
             iters += __shfl_xor(iters, off);
             rays += __shfl_xor(rays, off);
+            evals += __shfl_xor(evals, off);
             mx = max(mx, __shfl_xor(mx, off));
             mn = min(mn, __shfl_xor(mn, off));
         }
@@ -219,6 +221,7 @@ struct WaveAcc {
             atomicMax(&stats[4], (unsigned long long)(0x7fffffff - mn));   // zero-initialised => store the complement
             atomicAdd(&stats[5], rays);
         }
+        if (lane_id() == 0 && evals) atomicAdd(&stats[10], evals);
     }
 };
 
@@ -428,6 +431,7 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
                             s_depth[cur][my_pix] = s.res.hit ? (float)s.res.t : 0.0f;
                             s_ih[cur][my_pix] = (uint32_t)s.res.iters | ((uint32_t)s.res.hit << 31);
                             store_raw(a, my_gi, s.res, nev);
+                            acc.evals += (unsigned)nev;
                         } else {
                             active = true;
                             started = true;
@@ -472,6 +476,7 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
                 s_depth[my_slot][my_pix] = s.res.hit ? (float)s.res.t : 0.0f;   // types.py:93
                 s_ih[my_slot][my_pix] = (uint32_t)s.res.iters | ((uint32_t)s.res.hit << 31);
                 store_raw(a, my_gi, s.res, nev);
+                acc.evals += (unsigned)nev;
             } else if (a.suspend_after > 0 && s.i >= a.suspend_after) {
                 park = true;
             } else if constexpr (INTERLEAVE) {
@@ -611,6 +616,7 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void resume_kernel(const KernelAr
                     a.iters[my_gi] = it;
                     a.hit[my_gi] = (uint8_t)h;
                     store_raw(a, my_gi, s.res, nev);
+                    acc.evals += (unsigned)nev;
                     acc.add(it, h);
                     atomicAdd(&s_hist[min(it, a.hist_bins - 1)], 1u);
                     if (a.tile_cost) {
@@ -836,6 +842,7 @@ __global__ __launch_bounds__(64 * kTeam) void resume_team_kernel(const KernelArg
                 a.iters[my_gi] = it;
                 a.hit[my_gi] = (uint8_t)h;
                 store_raw(a, my_gi, s.res, nev);
+                acc.evals += (unsigned)nev;
                 acc.add(it, h);
                 atomicAdd(&s_hist[min(it, a.hist_bins - 1)], 1u);
                 if (a.tile_cost) {

@@ -141,6 +141,7 @@ def test_evaluation_counts_match_the_reference(hip):
             out = hip.render(desc, want_evals=True)
             assert (out["iters"] == z[pre + "iters"]).all(), (sid, kid, sched)
             assert (out["evals"] == z[pre + "evals"]).all(), (sid, kid, sched, int((out["evals"] != z[pre + "evals"]).sum()))
+            assert out["stats"]["sum_evals"] == int(z[pre + "evals"].astype(np.int64).sum())      # in-kernel total
     # without full the final_sdf-only evaluations are skipped: never more evaluations, same iterations
     pre = "s10_k6_"
     m = z[pre + "meta"]
