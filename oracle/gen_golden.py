@@ -19,7 +19,7 @@ Layout of each frames_*.npz (keys prefixed "s{scene_id}_k{strategy_id}_"):
   cam     float64 (14,)       position, forward, right, up, half_width, half_height
   meta    float64 (8,)        W, H, row0, rows, max_iterations, hit_threshold, max_distance, lipschitz
 
-Usage:  python oracle/gen_golden.py [--only frames64|frames160|rows1080|sdf|stats|leak|viewpoints|evals]
+Usage:  python oracle/gen_golden.py [--only frames64|frames160|rows1080|sdf|stats|leak|viewpoints|evals|analytic]
 """
 from __future__ import annotations
 
@@ -201,6 +201,32 @@ def gen_evals(W=48, H=36, scene_ids=(0, 1, 9, 10, 12, 15)):
     np.savez_compressed(os.path.join(OUT, f"evals_{W}x{H}.npz"), **store)
 
 
+def gen_analytic(W=80, H=60):
+    """Closed-form depth / hit / normal of the reference's gpu/analytic.py (:74-208) for its four analytic scenes,
+    on the CPU camera's pixel-centre rays (its intersect_* functions take ray arrays; the module is loaded by
+    path because the gpu package's __init__ needs moderngl)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_analytic", os.path.join(REF, "raymarching_benchmark", "gpu", "analytic.py"))
+    ref = importlib.util.module_from_spec(spec)
+    ref.__package__ = "raymarching_benchmark.gpu"
+    spec.loader.exec_module(ref)
+    store = {}
+    for sid in (0, 1, 2, 3):
+        scene, _, cam, _, _ = wire(sid, 0, W, H)
+        c = cam14(cam)
+        u = (2.0 * (np.arange(W) + 0.5) / W - 1.0) * c[12]
+        v = (1.0 - 2.0 * (np.arange(H) + 0.5) / H) * c[13]
+        d = c[3:6][None, None, :] + c[6:9][None, None, :] * u[None, :, None] + c[9:12][None, None, :] * v[:, None, None]
+        d = d / np.sqrt((d * d).sum(2, keepdims=True))
+        depth, hit, normal = ref.ANALYTIC_SCENES[scene.name](c[0:3].copy(), d)
+        store[f"s{sid}_depth"] = depth.astype("<f8")
+        store[f"s{sid}_hitbits"] = np.packbits(hit)
+        store[f"s{sid}_normal"] = normal.astype("<f8")
+        store[f"s{sid}_cam"] = c
+        print(f"  [analytic] {scene.name}: {int(hit.sum())} hits", flush=True)
+    np.savez_compressed(os.path.join(OUT, f"analytic_{W}x{H}.npz"), **store)
+
+
 def gen_viewpoints():
     """The reference's curated viewpoints (viewpoints.py:41-140) for every catalogue scene, as data."""
     from raymarching_benchmark.viewpoints import viewpoints_for
@@ -225,6 +251,8 @@ def main():
         gen_viewpoints()
     if a.only in ("all", "evals"):
         gen_evals()
+    if a.only in ("all", "analytic"):
+        gen_analytic()
     if a.only in ("all", "sdf"):
         gen_sdf()
     if a.only in ("all", "frames64"):
