@@ -101,7 +101,7 @@ typedef struct RmStats {
     int32_t iter_max;
     int32_t iter_min;
     uint64_t iter_hist[RM_HIST_BINS];
-    uint64_t sum_evals; /* SDF evaluations of all rays (see RmOutputs.evals; 0 in rm_render_batch's per-frame stats) */
+    uint64_t sum_evals; /* SDF evaluations of all rays (see RmOutputs.evals; in batches only when the evals map is requested) */
 } RmStats;
 
 /* in: warmup, repeats (<= RM_MAX_TIMED).  out: per-launch kernel milliseconds measured with
@@ -218,6 +218,11 @@ int rm_set_queue_capacity(int64_t entries);
 #define RM_MAX_PASSES 3
 int rm_set_pass_timing(int enable);
 int rm_get_pass_ms(void* stream, int32_t* npasses, float* ms);
+
+/* rm_render_batch with an outputs record: depth / iters / hit as above plus the optional frame-major evals map
+ * (RmOutputs.evals; t_raw, final_sdf and block_var must be NULL).  With evals, stats[f].sum_evals is filled. */
+int rm_render_batch_outputs(const RmFrameDesc* shape, int32_t nframes, const double* cams, const RmMarchConfig* configs,
+                            const RmOutputs* out, RmStats* stats, float* ms_total);
 
 /* Library-owned device frame buffers for callers without their own allocator. */
 int rm_alloc_frame(int32_t width, int32_t rows, void** d_depth, void** d_iters, void** d_hit);

@@ -25,7 +25,7 @@ EXPORTS = [
     "rm_init", "rm_shutdown", "rm_last_error", "rm_device_info", "rm_num_scenes", "rm_num_strategies",
     "rm_sdf_eval", "rm_march_rays", "rm_march_rays_team", "rm_render", "rm_render_outputs", "rm_render_device", "rm_stats_device_bytes",
     "rm_read_stats", "rm_bench_device", "rm_alloc_frame", "rm_free_frame", "rm_copy_frame_to_host",
-    "rm_bench_store_path", "rm_render_batch", "rm_set_pass_timing", "rm_get_pass_ms", "rm_set_queue_capacity",
+    "rm_bench_store_path", "rm_render_batch", "rm_render_batch_outputs", "rm_set_pass_timing", "rm_get_pass_ms", "rm_set_queue_capacity",
 ]
 
 
@@ -115,6 +115,8 @@ def load() -> ctypes.CDLL:
                                       ctypes.POINTER(RmTiming)]
         L.rm_render_batch.argtypes = [ctypes.POINTER(RmFrameDesc), ctypes.c_int32, dp, ctypes.POINTER(RmMarchConfig),
                                       vp, vp, vp, ctypes.POINTER(RmStats), ctypes.POINTER(ctypes.c_float)]
+        L.rm_render_batch_outputs.argtypes = [ctypes.POINTER(RmFrameDesc), ctypes.c_int32, dp, ctypes.POINTER(RmMarchConfig),
+                                              ctypes.POINTER(RmOutputs), ctypes.POINTER(RmStats), ctypes.POINTER(ctypes.c_float)]
         L.rm_alloc_frame.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(vp), ctypes.POINTER(vp),
                                      ctypes.POINTER(vp)]
         L.rm_free_frame.argtypes = [vp, vp, vp]
@@ -237,9 +239,9 @@ def render(desc: RmFrameDesc, want_t_raw=False, want_final_sdf=False, want_block
     return out
 
 
-def render_batch(shape: RmFrameDesc, cams, configs=None) -> dict:
-    """rm_render_batch: `cams` is (n, 14); `configs` an optional list of dicts / RmMarchConfig (one per
-    frame).  Returns frame-major depth / iters / hit arrays (n, rows, W), per-frame stats and ms_total."""
+def render_batch(shape: RmFrameDesc, cams, configs=None, want_evals=False) -> dict:
+    """rm_render_batch_outputs: `cams` is (n, 14); `configs` an optional list of dicts / RmMarchConfig (one per
+    frame).  Returns frame-major depth / iters / hit (/ evals) arrays (n, rows, W), per-frame stats and ms_total."""
     L = init()
     cams = np.ascontiguousarray(cams, dtype=np.float64).reshape(-1, 14)
     n = len(cams)
@@ -260,8 +262,11 @@ def render_batch(shape: RmFrameDesc, cams, configs=None) -> dict:
                                            float(c.get("lipschitz", 1.0)))
     st = (RmStats * n)()
     ms = ctypes.c_float(0.0)
-    check(L.rm_render_batch(ctypes.byref(shape), n, cams.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), cfg_arr,
-                            _ptr(out["depth"]), _ptr(out["iters"]), _ptr(out["hit"]), st, ctypes.byref(ms)))
+    out["evals"] = np.empty((n, rows, W), np.int32) if want_evals else None
+    o = RmOutputs(out["depth"].ctypes.data, out["iters"].ctypes.data, out["hit"].ctypes.data, None, None, None,
+                  out["evals"].ctypes.data if want_evals else None)
+    check(L.rm_render_batch_outputs(ctypes.byref(shape), n, cams.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), cfg_arr,
+                                    ctypes.byref(o), st, ctypes.byref(ms)))
     out["stats"] = [stats_dict(st[i]) for i in range(n)]
     out["ms_total"] = float(ms.value)
     return out

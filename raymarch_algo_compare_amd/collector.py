@@ -42,7 +42,7 @@ class HipCollector:
         return _native.render(desc, want_t_raw=self.full, want_final_sdf=self.full, warmup=warmup,
                               repeats=repeats)
 
-    def benchmark_batch(self, strategy: StrategyInfo, scene: SceneInfo, cameras, configs=None):
+    def benchmark_batch(self, strategy: StrategyInfo, scene: SceneInfo, cameras, configs=None, want_evals: bool = False):
         """Render one frame per camera (optionally one MarchConfig per frame) in ONE launch
         (rm_render_batch) and return a RayMarchStats per frame -- the shape of the reference's sweeps
         over curated viewpoints and iteration-budget / epsilon levels (viewpoints.py:41-140,
@@ -64,13 +64,14 @@ class HipCollector:
                          max_distance=self.config.max_distance, lipschitz=self._lipschitz(strategy))] * len(cameras)
         shape = _native.make_desc(scene.id, strategy.id, cameras[0].params14(), w, h, **self.tuning)
         start = time.perf_counter()
-        out = _native.render_batch(shape, np.stack([c.params14() for c in cameras]), cfgs)
+        out = _native.render_batch(shape, np.stack([c.params14() for c in cameras]), cfgs, want_evals=want_evals)
         elapsed = time.perf_counter() - start
         res = []
         for i in range(len(cameras)):
             st = RayMarchStats(strategy_name=strategy.short_name, scene_name=scene.name)
             st.compute_from_maps(out["iters"][i], out["hit"][i], out["depth"][i], elapsed / len(cameras))
             st.kernel_ms = out["ms_total"] / len(cameras)
+            st.evals_map = out["evals"][i] if want_evals else None       # SDF evaluations per ray (RmOutputs.evals)
             res.append(st)
         return res
 

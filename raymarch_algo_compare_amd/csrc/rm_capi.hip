@@ -722,9 +722,15 @@ int rm_bench_device(const RmFrameDesc* d, void* d_depth, void* d_iters, void* d_
     return RM_OK;
 }
 
-int rm_render_batch(const RmFrameDesc* shape, int32_t nframes, const double* cams, const RmMarchConfig* configs,
-                    float* depth, int32_t* iters, uint8_t* hit, RmStats* stats, float* ms_total)
+int rm_render_batch_outputs(const RmFrameDesc* shape, int32_t nframes, const double* cams, const RmMarchConfig* configs,
+                            const RmOutputs* o, RmStats* stats, float* ms_total)
 {
+    if (!o) return fail(RM_E_BAD_ARG, "outputs record is NULL");
+    if (o->t_raw || o->final_sdf || o->block_var) return fail(RM_E_BAD_ARG, "batches return depth, iters, hit and evals only");
+    float* const depth = o->depth;
+    int32_t* const iters = o->iters;
+    uint8_t* const hit = o->hit;
+    int32_t* const evals = o->evals;
     int rc = check_ready();
     if (rc) return rc;
     if ((rc = check_desc(shape))) return rc;
@@ -743,6 +749,7 @@ int rm_render_batch(const RmFrameDesc* shape, int32_t nframes, const double* cam
     if ((rc = g.depth.ensure(total * 4 + 16)) || (rc = g.iters.ensure(total * 4 + 16)) || (rc = g.hit.ensure(total + 16)) ||
         (rc = g.bstats.ensure(sizeof(rm::FrameParams) * (size_t)nframes)))
         return rc;
+    if (evals && (rc = g.evals.ensure(total * 4 + 16))) return rc;
     // the frame table: one camera + march configuration per frame
     std::vector<rm::FrameParams> fp((size_t)nframes);
     for (int f = 0; f < nframes; ++f) {
@@ -765,6 +772,7 @@ int rm_render_batch(const RmFrameDesc* shape, int32_t nframes, const double* cam
     a.frames = (const rm::FrameParams*)g.bstats.p;
     a.nframes = nframes;
     a.full = full;
+    a.evals = evals ? (int32_t*)g.evals.p : nullptr;
     if (d.grid_waves <= 0) {      // the batch is one big launch: size the persistent grid for all its tiles
         const long long ntiles = (long long)a.tiles_per_frame * nframes;
         int per_cu = 0;
@@ -779,6 +787,7 @@ int rm_render_batch(const RmFrameDesc* shape, int32_t nframes, const double* cam
     HIP_TRY(hipMemcpyAsync(depth, g.depth.p, total * 4, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipMemcpyAsync(iters, g.iters.p, total * 4, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipMemcpyAsync(hit, g.hit.p, total, hipMemcpyDeviceToHost, g.stream));
+    if (evals) HIP_TRY(hipMemcpyAsync(evals, g.evals.p, total * 4, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
     if (ms_total) HIP_TRY(hipEventElapsedTime(ms_total, g.ev[0], g.ev[1]));
     if (stats) {
@@ -797,6 +806,8 @@ int rm_render_batch(const RmFrameDesc* shape, int32_t nframes, const double* cam
                 st.iter_min = std::min(st.iter_min, it[i]);
                 st.iter_hist[std::min<int32_t>(std::max<int32_t>(it[i], 0), RM_HIST_BINS - 1)] += 1;
             }
+            if (evals)
+                for (size_t i = 0; i < n; ++i) st.sum_evals += (uint64_t)evals[(size_t)f * n + i];
         }
     }
     return RM_OK;
@@ -835,6 +846,15 @@ int rm_get_pass_ms(void* stream, int32_t* npasses, float* ms)
     *npasses = g.pass_count;
     for (int i = 0; i < g.pass_count; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], g.pev[i], g.pev[i + 1]));
     return RM_OK;
+}
+
+int rm_render_batch(const RmFrameDesc* shape, int32_t nframes, const double* cams, const RmMarchConfig* configs,
+                    float* depth, int32_t* iters, uint8_t* hit, RmStats* stats, float* ms_total)
+{
+    RmOutputs o;
+    memset(&o, 0, sizeof o);
+    o.depth = depth; o.iters = iters; o.hit = hit;
+    return rm_render_batch_outputs(shape, nframes, cams, configs, &o, stats, ms_total);
 }
 
 int rm_alloc_frame(int32_t width, int32_t rows, void** d_depth, void** d_iters, void** d_hit)

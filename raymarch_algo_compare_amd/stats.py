@@ -52,6 +52,7 @@ class RayMarchStats:
     depth_map: Optional[np.ndarray] = None
     # extras of this engine (not in the reference)
     kernel_ms: Optional[float] = None          # hipEvent time of the render kernel
+    evals_map: Optional[np.ndarray] = None     # SDF evaluations per ray, when requested (not a reference field)
 
     def compute_from_maps(self, iters: np.ndarray, hit: np.ndarray, depth: np.ndarray,
                           elapsed_seconds: float, final_sdf: Optional[np.ndarray] = None,

@@ -7,8 +7,8 @@ are bound by the latency of their longest ray, so here all viewpoints x all leve
 strategy) go through ONE rm_render_batch launch (per-frame camera + march configuration, the tails of
 the frames overlap) and the rows are cut from the returned maps on the host.
 
-A row holds the identifiers, the level, the iteration statistics the reference records (mean / median
-/ p95 / max, sweep.py:78-81), its adjacent-pixel divergence proxy (sweep.py:84-93), the hit rate and
+A row holds the identifiers, the level, the iteration and SDF-evaluation statistics the reference records
+(mean / median / p95 / max, sweep.py:78-81, :239-245), its adjacent-pixel divergence proxy (sweep.py:84-93), the hit rate and
 the error against the finest level of the same viewpoint (the finest level stands in for the
 reference's separately rendered ground truth: mean |depth - depth_finest| over common hits and the
 number of pixels whose hit flag differs).  Arithmetic is the CPU path's fp64, so rows are comparable
@@ -37,7 +37,8 @@ DEFAULT_BUDGETS = [32, 64, 128, 256, 512]                       # reference swee
 DEFAULT_EPSILONS = [1e-2, 3e-3, 1e-3, 3e-4, 1e-4, 3e-5, 1e-5]   # reference sweep.py:54
 
 ROW_FIELDS = ["scene", "strategy", "viewpoint", "category", "sweep_axis", "level", "max_iterations", "hit_threshold",
-              "width", "height", "iters_mean", "iters_median", "iters_p95", "iters_max", "divergence_proxy", "hit_rate",
+              "width", "height", "iters_mean", "iters_median", "iters_p95", "iters_max", "evals_mean", "evals_median", "evals_p95", "evals_max",
+              "divergence_proxy", "hit_rate",
               "depth_mae_vs_finest", "hit_flips_vs_finest", "ms_per_frame"]
 
 
@@ -78,7 +79,7 @@ def sweep_cell(collector: HipCollector, scene, strategy, mode: str, levels, widt
             cams.append(cam)
             cfgs.append(mc)
             tags.append((vp, li, value, extra))
-    frames = collector.benchmark_batch(strategy, scene, cams, cfgs)
+    frames = collector.benchmark_batch(strategy, scene, cams, cfgs, want_evals=True)
     fin = finest_index(mode, levels)
     rows = []
     for i, ((vp, li, value, extra), st) in enumerate(zip(tags, frames)):
@@ -90,7 +91,12 @@ def sweep_cell(collector: HipCollector, scene, strategy, mode: str, levels, widt
             "sweep_axis": extra["sweep_axis"], "level": value, "max_iterations": extra["max_iterations"],
             "hit_threshold": extra["hit_threshold"], "width": width, "height": height,
             "iters_mean": float(it.mean()), "iters_median": float(np.median(it)), "iters_p95": float(np.percentile(it, 95)),
-            "iters_max": float(it.max()), "divergence_proxy": divergence_proxy(it), "hit_rate": float(st.hit_map.mean()),
+            "iters_max": float(it.max()),
+            # SDF evaluations per ray -- the workload the iteration count under-reports for Segment / RevAA / Hybrid
+            # (reference sweep.py:239-245 records the same distribution from its capture)
+            "evals_mean": float(st.evals_map.mean()), "evals_median": float(np.median(st.evals_map)),
+            "evals_p95": float(np.percentile(st.evals_map, 95)), "evals_max": float(st.evals_map.max()),
+            "divergence_proxy": divergence_proxy(it), "hit_rate": float(st.hit_map.mean()),
             "depth_mae_vs_finest": float(np.abs(st.depth_map[both] - ref.depth_map[both]).mean()) if both.any() else 0.0,
             "hit_flips_vs_finest": int((st.hit_map != ref.hit_map).sum()),
             "ms_per_frame": float(st.kernel_ms),

@@ -123,8 +123,10 @@ def test_sweep_cells_equal_single_renders(hip, tmp_path):
         cam = Camera(vp.position, vp.target, vp.up, 60.0, w, h).params14()
         lip = (sc.lipschitz or 1.0) if st.key == "Segment" else 1.0
         one = hip.render(hip.make_desc(sc.id, st.id, cam, w, h, max_iterations=r["max_iterations"],
-                                       hit_threshold=r["hit_threshold"], lipschitz=lip))
+                                       hit_threshold=r["hit_threshold"], lipschitz=lip), want_evals=True)
         assert r["iters_mean"] == float(one["iters"].mean()) and r["iters_max"] == float(one["iters"].max()), r
+        assert r["evals_mean"] == float(one["evals"].mean()) and r["evals_max"] == float(one["evals"].max()), r
+        assert r["evals_mean"] >= r["iters_mean"] or r["strategy"] != "Standard"
         assert r["hit_rate"] == float((one["hit"] > 0).mean()) and r["divergence_proxy"] == sweep.divergence_proxy(one["iters"])
         if r["max_iterations"] == 512:
             assert r["depth_mae_vs_finest"] == 0.0 and r["hit_flips_vs_finest"] == 0
