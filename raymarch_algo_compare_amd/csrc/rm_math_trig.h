@@ -105,10 +105,13 @@ RM_MATH_HD void rm_sincos(double x, double* sin_out, double* cos_out)
     typedef SinCosK K;
     const uint32_t k = (uint32_t)(rm_asuint64(x) >> 32) & 0x7fffffffu;
     const double ax = rm_fabs(x);
-    // range 3: reduce_sincos
+    const bool r1 = k < 0x3feb6000u;
+    const bool r2 = !r1 & (k < 0x400368fdu);
+    // range 3: reduce_sincos.  Range 1 (|x| < 0.855469: no reduction, a = x, da = 0, n = 0) is folded into it by
+    // forcing the multiple of pi/2 to zero: every product with xn = 0 vanishes exactly, so b == x and db == +0.
     const double t = rm_fma(x, K::hpinv, K::toint);
-    const double xn = t - K::toint;
-    const uint32_t n = (uint32_t)rm_asuint64(t);
+    const double xn = r1 ? 0.0 : (t - K::toint);
+    const uint32_t n = r1 ? 0u : (uint32_t)rm_asuint64(t);
     const double y = rm_fnma(xn, K::mp2, rm_fnma(xn, K::mp1, x));
     const double t2 = rm_fnma(xn, K::pp3, y);
     double db = rm_fnma(K::pp3, xn, y - t2);
@@ -119,15 +122,12 @@ RM_MATH_HD void rm_sincos(double x, double* sin_out, double* cos_out)
     const double a2 = tt + K::hp1;
     const double da2 = (tt - a2) + K::hp1;
 
-    const bool r1 = k < 0x3feb6000u;
-    const bool r2 = !r1 & (k < 0x400368fdu);
     // single-level selects only (a nested ?: comes back from the compiler as a branch)
-    double aS = r2 ? a2 : b, daS = r2 ? da2 : db, aC = r2 ? tt : b, daC = r2 ? K::hp1 : db;
-    aS = r1 ? x : aS; daS = r1 ? 0.0 : daS; aC = r1 ? x : aC; daC = r1 ? 0.0 : daC;
+    const double aS = r2 ? a2 : b, daS = r2 ? da2 : db, aC = r2 ? tt : b, daC = r2 ? K::hp1 : db;
     const double dS = rm_do_sin(aS, daS);
     const double dC = rm_do_cos(aC, daC);
 
-    // range 3 routing: do_sincos(a, da, n) = (n & 1 ? do_cos : do_sin), negated when n & 2
+    // range 3 (and 1, n = 0) routing: do_sincos(a, da, n) = (n & 1 ? do_cos : do_sin), negated when n & 2
     const uint32_t m = n + 1u;
     double s3 = (n & 1u) ? dC : dS;
     s3 = (n & 2u) ? -s3 : s3;
@@ -135,8 +135,6 @@ RM_MATH_HD void rm_sincos(double x, double* sin_out, double* cos_out)
     c3 = (m & 2u) ? -c3 : c3;
     const double s2 = __builtin_copysign(dC, x);
     double s = r2 ? s2 : s3, c = r2 ? dS : c3;
-    s = r1 ? dS : s;
-    c = r1 ? dC : c;
     s = (k < 0x3e500000u) ? x : s;                      // |x| < 2^-26
     c = (k < 0x3e400000u) ? 1.0 : c;                    // |x| < 2^-27
     const double bad = __builtin_nan("");                // inf / nan -> nan; __branred range unclaimed
