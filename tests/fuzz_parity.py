@@ -2,7 +2,7 @@
 """Randomised parity campaign on a GPU box: random (scene, strategy), frame size, camera, march configuration and
 SCHEDULE knobs (evaluation mode, suspension budgets, resume mode, refill threshold, grid size, tile order, row
 shards) against the CPU oracle, bit for bit (iterations, hits, raw fp64 t, final_sdf, frame totals).
-usage: python tools/fuzz_parity.py [cases] [seed]      (test infrastructure: it loads oracle/)"""
+usage: python tests/fuzz_parity.py [cases] [seed]      (test infrastructure, lives under tests/: it loads oracle/)"""
 import json
 import os
 import sys

@@ -185,13 +185,12 @@ def test_union_scenes_team_form(hip):
 
 
 def test_randomised_parity_campaign(hip):
-    """150 random (scene, strategy, frame, camera, march configuration, schedule) cases of tools/fuzz_parity.py
+    """150 random (scene, strategy, frame, camera, march configuration, schedule) cases of tests/fuzz_parity.py
     against the pinned oracle: every combination of evaluation mode, suspension budgets, resume mode, refill
     threshold, grid sizes, tile order and row shard must give the reference's bits."""
     import importlib.util
     import os
-    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                                               "tools", "fuzz_parity.py"))
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_parity.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     rng = np.random.default_rng(2024)
