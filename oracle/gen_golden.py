@@ -19,7 +19,7 @@ Layout of each frames_*.npz (keys prefixed "s{scene_id}_k{strategy_id}_"):
   cam     float64 (14,)       position, forward, right, up, half_width, half_height
   meta    float64 (8,)        W, H, row0, rows, max_iterations, hit_threshold, max_distance, lipschitz
 
-Usage:  python oracle/gen_golden.py [--only frames64|frames160|rows1080|sdf|stats|leak|viewpoints|evals|analytic]
+Usage:  python oracle/gen_golden.py [--only frames64|frames160|rows1080|sdf|stats|leak|leakseq|schema|viewpoints|evals|analytic]
 """
 from __future__ import annotations
 
@@ -160,6 +160,62 @@ def gen_leak():
     np.savez_compressed(os.path.join(OUT, "frames_leak.npz"), **store)
 
 
+def leak_sequence(W, H, upto):
+    """Walk `--scene all` in catalogue order with ONE shared RenderConfig, as cli() does (main.py:167,206):
+    returns the RenderConfig as scene `upto` finds it (every earlier scene's suggestion applied)."""
+    rc = RenderConfig(width=W, height=H)
+    for sid in range(upto):
+        wire(sid, 0, W, H, rc)
+    return rc
+
+
+# (scene, strategy) cells whose camera is NOT the scene's own in `--scene all --strategy all` order
+# (SURVEY.md section 5f: scenes 2..9 see Grazing Plane's camera, 11 sees Mandelbulb's)
+LEAK_CELLS = [(2, 10), (3, 4), (5, 9), (6, 3), (8, 10), (9, 6), (11, 0), (11, 10)]
+LEAK_ROWS_1080 = [(2, 0), (9, 0), (11, 10)]
+
+
+def gen_leakseq():
+    """Cells of the CLI's leaked-camera sequence: whole frames at 64x48 and rows 536..543 of 1920x1080."""
+    mc = MarchConfig()
+    store, stats = {}, {}
+    for sid, kid in LEAK_CELLS:
+        rc = leak_sequence(64, 48, sid)
+        scene, strategy, cam, lip, _ = wire(sid, kid, 64, 48, rc)
+        res = march_rows(scene, strategy, cam, mc, 0, 48)
+        pack(f"s{sid}_k{kid}_", res, cam, mc, lip, 0, 48, store)
+        stats[f"s{sid}_k{kid}"] = stats_dict(scene, strategy, res, 64, 48)
+        print(f"  [leakseq] {scene.name} / {strategy.short_name}: camera {rc.camera_position} -> {rc.camera_target}, "
+              f"hits {stats[f's{sid}_k{kid}']['hit_count']}", flush=True)
+    np.savez_compressed(os.path.join(OUT, "frames_leakseq.npz"), **store)
+    with open(os.path.join(OUT, "stats_leakseq.json"), "w", encoding="utf-8") as f:
+        json.dump(stats, f, indent=1, ensure_ascii=False)
+    store = {}
+    for sid, kid in LEAK_ROWS_1080:
+        rc = leak_sequence(1920, 1080, sid)
+        scene, strategy, cam, lip, _ = wire(sid, kid, 1920, 1080, rc)
+        res = march_rows(scene, strategy, cam, mc, 536, 8)
+        pack(f"s{sid}_k{kid}_", res, cam, mc, lip, 536, 8, store)
+        print(f"  [leakrows1080] {scene.name} / {strategy.short_name}", flush=True)
+    np.savez_compressed(os.path.join(OUT, "frames_leakrows1080.npz"), **store)
+
+
+def gen_schema():
+    """Header row and index column of the nine matrix_*.csv files the reference ships under example/
+    (data files; BASELINE config 4 asks for CSVs identical in schema to these)."""
+    import csv
+    ex = os.path.join(REF, "example")
+    out = {}
+    for fn in sorted(os.listdir(ex)):
+        if fn.startswith("matrix_") and fn.endswith(".csv"):
+            with open(os.path.join(ex, fn), encoding="utf-8", newline="") as f:
+                rows = list(csv.reader(f))
+            out[fn] = {"header": rows[0], "index": [r[0] for r in rows[1:]]}
+    with open(os.path.join(OUT, "example_matrix_schema.json"), "w", encoding="utf-8") as f:
+        json.dump(out, f, indent=1, ensure_ascii=False)
+    print("example_matrix_schema.json:", len(out), "files")
+
+
 def gen_sdf(n=2000):
     """Per-scene SDF values at seeded random points (same generator idea as the
     reference's tests/test_scene_parity.py:88-102)."""
@@ -265,6 +321,10 @@ def main():
         gen_rows1080([(0, 0), (2, 0), (9, 0), (10, 0), (10, 4), (10, 6), (12, 0)])
     if a.only in ("all", "leak"):
         gen_leak()
+    if a.only in ("all", "leakseq"):
+        gen_leakseq()
+    if a.only in ("all", "schema"):
+        gen_schema()
     if a.only in ("all", "small"):
         # max_iterations=100, 16x12: the configuration of the reference's own smoke test
         # (tests/test_smoke.py:31-43), every registry key on the Sphere.

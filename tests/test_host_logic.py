@@ -105,3 +105,17 @@ def test_csv_and_json_schema(tmp_path):
         "gpu_time_sample_count", "gpu_warp_divergence", "gpu_width", "gpu_height"]
     assert np.load(os.path.join(out, "depth_map.npy")).dtype == np.float64
     assert safe_name("Menger Sponge (iter=3)") == "Menger_Sponge_(iter=3)"
+
+
+def test_csv_schema_is_the_reference_examples():
+    """tests/golden/example_matrix_schema.json = header row + index column of the nine matrix_*.csv the reference
+    ships under example/ (oracle/gen_golden.py --only schema): same file names, same sorted short-name columns,
+    same first-seen scene order as this package writes for the graded 14 x 9 run."""
+    from conftest import GOLDEN
+    schema = json.load(open(os.path.join(GOLDEN, "example_matrix_schema.json"), encoding="utf-8"))
+    assert sorted(schema) == sorted(f"matrix_{m}.csv" for m in CSV_METRICS)
+    cols = sorted(registry.get_strategy_by_name(k).short_name for k in registry.GRADED_STRATEGY_KEYS)
+    rows = [registry.SCENES[s].name for s in registry.GRADED_SCENE_IDS]
+    for fn, rec in schema.items():
+        assert rec["header"] == [""] + cols, fn
+        assert rec["index"] == rows, fn

@@ -15,7 +15,7 @@ def _render(g, sid, kid):
                          g["hit_threshold"], g["max_distance"], g["lipschitz"])
 
 
-@pytest.mark.parametrize("tag", ["64x48", "160x120", "rows1080", "leak", "16x12_it100"])
+@pytest.mark.parametrize("tag", ["64x48", "160x120", "rows1080", "leak", "leakseq", "leakrows1080", "16x12_it100"])
 def test_oracle_matches_reference(tag):
     G = golden_frames(tag)
     assert G.pairs
