@@ -35,15 +35,47 @@ extern "C" {
 #define RM_HIST_BINS 544 /* iterations histogram bins; counts >= RM_HIST_BINS-1 share the last bin */
 #define RM_MAX_TIMED 256
 
+/* The constructor arguments of the reference's strategy classes -- what `STRATEGIES[key](**kwargs)` takes and
+ * what its accelerator seam threads through as per-run uniform overrides (gpu/runner.py:108-124, swept by
+ * param_grid.py:20-27 / sweep.py:181,222-223) -- plus four constants the CPU march() bodies hold as literals.
+ * Defaults (rm_default_strategy_params) are the reference's; with them every result is bit-identical to the
+ * registry's no-argument instances.  A strategy reads only its own fields. */
+typedef struct RmStrategyParams {
+    double omega;                     /* 1.2   RelaxedSphereTracing(omega)                 strategies/relaxed_sphere.py:17 */
+    double ar_omega_min;              /* 1.0   AutoRelaxedSphereTracing(omega_min,          strategies/auto_relaxed.py:21-23 */
+    double ar_omega_max;              /* 2.0     omega_max, */
+    double ar_smoothing;              /* 0.7     smoothing, */
+    double ar_growth_rate;            /* 1.05    growth_rate, */
+    double ar_decay_rate;             /* 0.7     decay_rate) */
+    double beta;                      /* 0.3   SlopeAutoRelaxed(beta)                      strategies/slope_auto_relaxed.py:25 */
+    double overstep_min_step;         /* 0.01  OverstepBisectTracing(min_step_factor,       strategies/overstep_bisect.py:18 */
+    double hybrid_stuck_step_ratio;   /* 0.001 AdaptiveHybridTracing(stuck_step_ratio,      strategies/adaptive_hybrid.py:17-19 */
+    double hybrid_min_step;           /* 0.005   min_step_factor, */
+    double margin;                    /* 0.05  SkippingSpheresTracing: the literal `margin` of march() (skipping_spheres.py:30),
+                                               uniform `margin` of the GLSL seam (gpu/runner.py:115) */
+    double ar_omega_init;             /* 1.2   AutoRelaxedSphereTracing: the literal start value `omega = 1.2` of march() (auto_relaxed.py:41);
+                                               the GLSL seam's `omega` uniform drives its auto-relaxed marcher too (param_grid.py:23) */
+    int32_t overstep_bisection_steps; /* 16      bisection_steps)                           strategies/overstep_bisect.py:18 */
+    int32_t hybrid_stuck_threshold;   /* 5       stuck_threshold)                           strategies/adaptive_hybrid.py:17 */
+    int32_t segment_bisection_steps;  /* 8     SegmentTracing: the literal `range(8)` of march()      segment_tracing.py:79 */
+    int32_t revaa_bisection_steps;    /* 8     RevAAApproxTracing: the literal `range(8)` of march()  rev_affine.py:70 */
+} RmStrategyParams;
+
 /* MarchConfig (config.py:19-29) -- the three fields the CPU strategies read -- plus
- * SegmentTracing.lipschitz as wired by run_once (main.py:58-61).
- * full != 0 also produces MarchResult.final_sdf (costs the reference's tail evaluations). */
+ * SegmentTracing.lipschitz as wired by run_once (main.py:58-61) and the strategy's constructor arguments.
+ * full != 0 also produces MarchResult.final_sdf (costs the reference's tail evaluations).
+ * use_params == 0: `params` is ignored and every strategy constant has the reference's default (a zeroed
+ * record is therefore a valid default configuration); != 0: `params` is read (fill it with
+ * rm_default_strategy_params first and override what the run sweeps). */
 typedef struct RmMarchConfig {
     int32_t max_iterations; /* 512   */
     int32_t full;
     double hit_threshold;   /* 1e-4  */
     double max_distance;    /* 100.0 */
     double lipschitz;       /* 1.0   */
+    int32_t use_params;
+    int32_t reserved;       /* 0 */
+    RmStrategyParams params;
 } RmMarchConfig;
 
 /* One frame (or a row shard of it).  cam[14] = position, forward, right, up,
@@ -132,6 +164,8 @@ const char* rm_last_error(void);
 int rm_device_info(RmDeviceInfo* out);
 int rm_num_scenes(void);
 int rm_num_strategies(void);
+/* The reference's defaults (the values its registry's no-argument constructors use); never fails. */
+void rm_default_strategy_params(RmStrategyParams* out);
 
 /* SDFScene.sdf (scenes/base.py:29-32) over n points; host pointers, xyz is n x 3. */
 int rm_sdf_eval(int scene_id, const double* xyz, size_t n, double* out);

@@ -19,7 +19,7 @@ Layout of each frames_*.npz (keys prefixed "s{scene_id}_k{strategy_id}_"):
   cam     float64 (14,)       position, forward, right, up, half_width, half_height
   meta    float64 (8,)        W, H, row0, rows, max_iterations, hit_threshold, max_distance, lipschitz
 
-Usage:  python oracle/gen_golden.py [--only frames64|frames160|rows1080|sdf|stats|leak|leakseq|schema|viewpoints|evals|analytic]
+Usage:  python oracle/gen_golden.py [--only frames64|frames160|rows1080|sdf|stats|leak|leakseq|params|schema|viewpoints|evals|analytic]
 """
 from __future__ import annotations
 
@@ -216,6 +216,83 @@ def gen_schema():
     print("example_matrix_schema.json:", len(out), "files")
 
 
+# ---- non-default strategy parameters ---------------------------------------------------------------
+# Parameter names / order of RmStrategyParams (include/rm_hip.h) = rmo_cfg (oracle/rm_oracle.c).
+PARAM_ORDER = ["omega", "ar_omega_min", "ar_omega_max", "ar_smoothing", "ar_growth_rate", "ar_decay_rate", "beta",
+               "overstep_min_step", "hybrid_stuck_step_ratio", "hybrid_min_step", "margin", "ar_omega_init",
+               "overstep_bisection_steps", "hybrid_stuck_threshold", "segment_bisection_steps", "revaa_bisection_steps"]
+PARAM_DEFAULTS = dict(omega=1.2, ar_omega_min=1.0, ar_omega_max=2.0, ar_smoothing=0.7, ar_growth_rate=1.05,
+                      ar_decay_rate=0.7, beta=0.3, overstep_min_step=0.01, hybrid_stuck_step_ratio=0.001,
+                      hybrid_min_step=0.005, margin=0.05, ar_omega_init=1.2, overstep_bisection_steps=16, hybrid_stuck_threshold=5,
+                      segment_bisection_steps=8, revaa_bisection_steps=8)
+
+
+def with_literal(cls, old, new):
+    """The reference class with ONE literal of its march() replaced: the method is rebuilt from the reference's
+    own code object with that constant swapped (types.CodeType.replace), nothing is re-typed.  Used for the four
+    parameters the CPU strategies hold as literals (skipping_spheres.py:30 `margin = 0.05`, auto_relaxed.py:41
+    `omega = 1.2`, segment_tracing.py:79 and rev_affine.py:70 `range(8)`); the GLSL seam exposes `margin` as a uniform (gpu/runner.py:115)."""
+    import types
+    code = cls.march.__code__
+    assert sum(1 for c in code.co_consts if type(c) is type(old) and c == old) == 1, (cls.__name__, old, code.co_consts)
+    consts = tuple(new if (type(c) is type(old) and c == old) else c for c in code.co_consts)
+    fn = types.FunctionType(code.replace(co_consts=consts), cls.march.__globals__, "march", cls.march.__defaults__,
+                            cls.march.__closure__)
+    return type(cls.__name__ + "Lit", (cls,), {"march": fn})
+
+
+# (strategy id, constructor kwargs / literal swaps, RmStrategyParams overrides): >= 3 non-default settings per
+# tunable strategy; omega / margin values are the reference's own grid (param_grid.py:20-27)
+PARAM_CASES = (
+    [(1, dict(omega=w), None, dict(omega=w)) for w in (1.4, 1.6, 1.8)] +
+    [(2, dict(omega_min=a, omega_max=b, smoothing=c, growth_rate=d, decay_rate=e), None,
+      dict(ar_omega_min=a, ar_omega_max=b, ar_smoothing=c, ar_growth_rate=d, ar_decay_rate=e))
+     for a, b, c, d, e in ((1.0, 1.6, 0.5, 1.1, 0.5), (1.1, 2.5, 0.9, 1.02, 0.8), (1.0, 3.0, 0.3, 1.2, 0.9))] +
+    [(3, dict(beta=b), None, dict(beta=b)) for b in (0.1, 0.5, 0.9)] +
+    [(6, dict(min_step_factor=m, bisection_steps=n), None, dict(overstep_min_step=m, overstep_bisection_steps=n))
+     for m, n in ((0.02, 8), (0.005, 24), (0.05, 4), (0.01, 0))] +
+    [(9, dict(stuck_threshold=k, stuck_step_ratio=r, min_step_factor=m), None,
+      dict(hybrid_stuck_threshold=k, hybrid_stuck_step_ratio=r, hybrid_min_step=m))
+     for k, r, m in ((3, 0.01, 0.01), (8, 0.0005, 0.002), (2, 0.005, 0.02))] +
+    [(7, {}, (0.05, m), dict(margin=m)) for m in (0.02, 0.1, 0.2)] +
+    [(2, {}, (1.2, w), dict(ar_omega_init=w)) for w in (1.4, 1.6, 1.8)] +
+    [(10, {}, (8, n), dict(segment_bisection_steps=n)) for n in (3, 12, 0)] +
+    [(8, {}, (8, n), dict(revaa_bisection_steps=n)) for n in (3, 12, 0)]
+)
+PARAM_SCENES = (0, 2, 9, 10, 12)
+
+
+def gen_params(W=48, H=36):
+    """Frames marched by the reference's strategy classes constructed with NON-default arguments."""
+    mc = MarchConfig()
+    store = {}
+    n = 0
+    for kid, kwargs, literal, overrides in PARAM_CASES:
+        cls = STRATEGIES[STRAT_KEYS[kid]]
+        if literal is not None:
+            cls = with_literal(cls, *literal)
+        for sid in PARAM_SCENES:
+            scene, _, cam, _, _ = wire(sid, kid, W, H)
+            strategy = cls(**kwargs)
+            lip = 1.0
+            if hasattr(strategy, "lipschitz"):                            # main.py:58-61
+                bound = scene.known_lipschitz_bound()
+                if bound is not None:
+                    strategy.lipschitz = bound
+                lip = float(strategy.lipschitz)
+            res = march_rows(scene, strategy, cam, mc, 0, H)
+            pre = f"c{n}_"
+            pack(pre, res, cam, mc, lip, 0, H, store)
+            prm = dict(PARAM_DEFAULTS, **overrides)
+            store[pre + "ids"] = np.array([sid, kid], dtype=np.int32)
+            store[pre + "prm"] = np.array([float(prm[k]) for k in PARAM_ORDER], dtype=np.float64)
+            print(f"  [params] case {n}: {scene.name} / {strategy.short_name} {overrides}: hits "
+                  f"{sum(1 for r in res if r.hit)} iterations {sum(r.iterations for r in res)}", flush=True)
+            n += 1
+    store["ncases"] = np.array([n], dtype=np.int32)
+    np.savez_compressed(os.path.join(OUT, f"frames_params_{W}x{H}.npz"), **store)
+
+
 def gen_sdf(n=2000):
     """Per-scene SDF values at seeded random points (same generator idea as the
     reference's tests/test_scene_parity.py:88-102)."""
@@ -323,6 +400,8 @@ def main():
         gen_leak()
     if a.only in ("all", "leakseq"):
         gen_leakseq()
+    if a.only in ("all", "params"):
+        gen_params()
     if a.only in ("all", "schema"):
         gen_schema()
     if a.only in ("all", "small"):

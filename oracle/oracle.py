@@ -31,13 +31,41 @@ STRATEGY_KEYS = [
 ]
 
 
+# Constructor arguments of the reference's strategies (relaxed_sphere.py:17, auto_relaxed.py:21-23,
+# slope_auto_relaxed.py:25, overstep_bisect.py:18, adaptive_hybrid.py:17-19) and four literals of their
+# march() bodies (skipping_spheres.py:30, auto_relaxed.py:41, segment_tracing.py:79, rev_affine.py:70); rmo_cfg order.
+PARAM_FIELDS = [
+    ("omega", ctypes.c_double, 1.2), ("ar_omega_min", ctypes.c_double, 1.0), ("ar_omega_max", ctypes.c_double, 2.0),
+    ("ar_smoothing", ctypes.c_double, 0.7), ("ar_growth_rate", ctypes.c_double, 1.05),
+    ("ar_decay_rate", ctypes.c_double, 0.7), ("beta", ctypes.c_double, 0.3),
+    ("overstep_min_step", ctypes.c_double, 0.01), ("hybrid_stuck_step_ratio", ctypes.c_double, 0.001),
+    ("hybrid_min_step", ctypes.c_double, 0.005), ("margin", ctypes.c_double, 0.05),
+    ("ar_omega_init", ctypes.c_double, 1.2),
+    ("overstep_bisection_steps", ctypes.c_int32, 16), ("hybrid_stuck_threshold", ctypes.c_int32, 5),
+    ("segment_bisection_steps", ctypes.c_int32, 8), ("revaa_bisection_steps", ctypes.c_int32, 8),
+]
+DEFAULT_PARAMS = {n: d for n, _, d in PARAM_FIELDS}
+
+
 class _Cfg(ctypes.Structure):
     _fields_ = [
         ("max_iterations", ctypes.c_int32),
         ("hit_threshold", ctypes.c_double),
         ("max_distance", ctypes.c_double),
         ("lipschitz", ctypes.c_double),
-    ]
+    ] + [(n, t) for n, t, _ in PARAM_FIELDS]
+
+
+def _cfg(max_iterations, hit_threshold, max_distance, lipschitz, params=None) -> _Cfg:
+    c = _Cfg(int(max_iterations), float(hit_threshold), float(max_distance), float(lipschitz))
+    vals = dict(DEFAULT_PARAMS)
+    for k, v in (params or {}).items():
+        if k not in vals:
+            raise KeyError(f"unknown strategy parameter {k!r}")
+        vals[k] = v
+    for n, t, _ in PARAM_FIELDS:
+        setattr(c, n, int(vals[n]) if t is ctypes.c_int32 else float(vals[n]))
+    return c
 
 
 def build(force: bool = False) -> str:
@@ -125,9 +153,9 @@ def sdf_eval(scene_id: int, pts: np.ndarray) -> np.ndarray:
 def render(scene_id: int, strategy_id: int, cam14: np.ndarray, width: int, height: int,
            row0: int = 0, rows: int | None = None, max_iterations: int = 512,
            hit_threshold: float = 1e-4, max_distance: float = 100.0, lipschitz: float = 1.0,
-           nthreads: int = 1) -> OracleFrame:
+           nthreads: int = 1, params: dict | None = None) -> OracleFrame:
     rows = height - row0 if rows is None else rows
-    cfg = _Cfg(max_iterations, hit_threshold, max_distance, lipschitz)
+    cfg = _cfg(max_iterations, hit_threshold, max_distance, lipschitz, params)
     n = rows * width
     hit = np.empty(n, dtype=np.uint8)
     t = np.empty(n, dtype=np.float64)
@@ -147,11 +175,11 @@ def render(scene_id: int, strategy_id: int, cam14: np.ndarray, width: int, heigh
 
 def march_rays(scene_id: int, strategy_id: int, origins: np.ndarray, dirs: np.ndarray,
                max_iterations: int = 512, hit_threshold: float = 1e-4, max_distance: float = 100.0,
-               lipschitz: float = 1.0):
+               lipschitz: float = 1.0, params: dict | None = None):
     origins = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
     dirs = np.ascontiguousarray(dirs, dtype=np.float64).reshape(-1, 3)
     n = len(origins)
-    cfg = _Cfg(max_iterations, hit_threshold, max_distance, lipschitz)
+    cfg = _cfg(max_iterations, hit_threshold, max_distance, lipschitz, params)
     hit = np.empty(n, dtype=np.uint8)
     t = np.empty(n, dtype=np.float64)
     iters = np.empty(n, dtype=np.int32)

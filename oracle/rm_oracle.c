@@ -302,6 +302,24 @@ typedef struct {
     double hit_threshold;     /* config.py:22 */
     double max_distance;      /* config.py:23 */
     double lipschitz;         /* SegmentTracing.lipschitz, wired by main.py:58-61 */
+    /* Constructor arguments of the reference's strategies (defaults in the comments), then four
+     * constants their march() bodies hold as literals.  Same order as RmStrategyParams (include/rm_hip.h). */
+    double omega;                   /* RelaxedSphereTracing(omega=1.2)                 relaxed_sphere.py:17 */
+    double ar_omega_min;            /* AutoRelaxedSphereTracing(omega_min=1.0,          auto_relaxed.py:21-23 */
+    double ar_omega_max;            /*   omega_max=2.0, */
+    double ar_smoothing;            /*   smoothing=0.7, */
+    double ar_growth_rate;          /*   growth_rate=1.05, */
+    double ar_decay_rate;           /*   decay_rate=0.7) */
+    double beta;                    /* SlopeAutoRelaxed(beta=0.3)                      slope_auto_relaxed.py:25 */
+    double overstep_min_step;       /* OverstepBisectTracing(min_step_factor=0.01,      overstep_bisect.py:18 */
+    double hybrid_stuck_step_ratio; /* AdaptiveHybridTracing(stuck_step_ratio=0.001,    adaptive_hybrid.py:17-19 */
+    double hybrid_min_step;         /*   min_step_factor=0.005, */
+    double margin;                  /* `margin = 0.05`, a literal of SkippingSpheresTracing.march    skipping_spheres.py:30 */
+    double ar_omega_init;           /* `omega = 1.2`, a literal of AutoRelaxedSphereTracing.march    auto_relaxed.py:41 */
+    int32_t overstep_bisection_steps; /* bisection_steps=16)                            overstep_bisect.py:18 */
+    int32_t hybrid_stuck_threshold;   /* stuck_threshold=5)                             adaptive_hybrid.py:17 */
+    int32_t segment_bisection_steps;  /* `range(8)`, a literal of SegmentTracing.march  segment_tracing.py:79 */
+    int32_t revaa_bisection_steps;    /* `range(8)`, a literal of RevAAApproxTracing.march  rev_affine.py:70 */
 } rmo_cfg;
 
 typedef struct { int hit; double t; int32_t iterations; double final_sdf; } result_t;
@@ -325,10 +343,10 @@ static result_t st_standard(const ray_t *ray, sdf_fn sdf, const rmo_cfg *c)
     return mk(0, t, iterations, sdf(ray_at(ray, t)));
 }
 
-/* strategies/relaxed_sphere.py:28-70 (omega = 1.2) */
+/* strategies/relaxed_sphere.py:28-70 */
 static result_t st_relaxed(const ray_t *ray, sdf_fn sdf, const rmo_cfg *c)
 {
-    double t = 0.0, prev_d = 0.0, omega = 1.2; int32_t iterations = 0;
+    double t = 0.0, prev_d = 0.0, omega = c->omega; int32_t iterations = 0;
     for (int32_t i = 0; i < c->max_iterations; ++i) {
         iterations = i + 1;
         double d = sdf(ray_at(ray, t));
@@ -346,8 +364,9 @@ static result_t st_relaxed(const ray_t *ray, sdf_fn sdf, const rmo_cfg *c)
 /* strategies/auto_relaxed.py:38-90 */
 static result_t st_auto_relaxed(const ray_t *ray, sdf_fn sdf, const rmo_cfg *c)
 {
-    const double omega_min = 1.0, omega_max = 2.0, smoothing = 0.7, growth = 1.05, decay = 0.7;
-    double t = 0.0, omega = 1.2, prev_d = INFINITY, ema = 1.0; int32_t iterations = 0;
+    const double omega_min = c->ar_omega_min, omega_max = c->ar_omega_max, smoothing = c->ar_smoothing,
+                 growth = c->ar_growth_rate, decay = c->ar_decay_rate;
+    double t = 0.0, omega = c->ar_omega_init, prev_d = INFINITY, ema = 1.0; int32_t iterations = 0;
     for (int32_t i = 0; i < c->max_iterations; ++i) {
         iterations = i + 1;
         double d = sdf(ray_at(ray, t));
@@ -367,10 +386,10 @@ static result_t st_auto_relaxed(const ray_t *ray, sdf_fn sdf, const rmo_cfg *c)
     return mk(0, t, iterations, sdf(ray_at(ray, t)));
 }
 
-/* strategies/slope_auto_relaxed.py:41-115 (beta = 0.3) */
+/* strategies/slope_auto_relaxed.py:41-115 */
 static result_t st_slope(const ray_t *ray, sdf_fn sdf, const rmo_cfg *c)
 {
-    const double beta = 0.3;
+    const double beta = c->beta;
     double t = 0.0; int32_t iterations = 0;
     double r = sdf(ray_at(ray, t));
     double z = r, m = -1.0;
@@ -459,10 +478,10 @@ static result_t st_curvature(const ray_t *ray, sdf_fn sdf, const rmo_cfg *c)
     return mk(0, t, iterations, sdf(ray_at(ray, t)));
 }
 
-/* strategies/overstep_bisect.py:30-121 (min_step 0.01, 16 bisection steps) */
+/* strategies/overstep_bisect.py:30-121 */
 static result_t st_overstep_bisect(const ray_t *ray, sdf_fn sdf, const rmo_cfg *c)
 {
-    const double min_step = 0.01; const int bis = 16;
+    const double min_step = c->overstep_min_step; const int bis = c->overstep_bisection_steps;
     double t = 0.0, t_near = 0.0, t_far = -1.0; int32_t iterations = 0;
     int32_t budget = c->max_iterations - bis;
     for (int32_t i = 0; i < budget; ++i) {
@@ -495,7 +514,8 @@ static result_t st_overstep_bisect(const ray_t *ray, sdf_fn sdf, const rmo_cfg *
 /* strategies/adaptive_hybrid.py:35-149 */
 static result_t st_hybrid(const ray_t *ray, sdf_fn sdf, const rmo_cfg *c)
 {
-    const int stuck_threshold = 5; const double stuck_ratio = 0.001, min_step = 0.005;
+    const int stuck_threshold = c->hybrid_stuck_threshold;
+    const double stuck_ratio = c->hybrid_stuck_step_ratio, min_step = c->hybrid_min_step;
     enum { SPHERE, OVERSTEP, BISECT } mode = SPHERE;
     double t = 0.0, t_near = 0.0, t_far = -1.0; int32_t iterations = 0; int small = 0;
     for (int32_t i = 0; i < c->max_iterations; ++i) {
@@ -544,7 +564,7 @@ static result_t st_segment(const ray_t *ray, sdf_fn sdf, const rmo_cfg *c)
         if (fabs(d_end) < c->hit_threshold) { t += candidate; return mk(1, t, iterations, d_end); }
         if (d_end < 0.0) {
             double t_lo = t, t_hi = t + candidate;
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < c->segment_bisection_steps; ++k) {
                 iterations += 1;
                 double t_mid = (t_lo + t_hi) * 0.5;
                 double d_mid = sdf(ray_at(ray, t_mid));
@@ -564,7 +584,7 @@ static result_t st_segment(const ray_t *ray, sdf_fn sdf, const rmo_cfg *c)
 /* strategies/skipping_spheres.py:25-72 */
 static result_t st_skipping(const ray_t *ray, sdf_fn sdf, const rmo_cfg *c)
 {
-    const double margin = 0.05;
+    const double margin = c->margin;
     double t = 0.0; int32_t iterations = 0;
     int32_t coarse = (c->max_iterations * 2) / 3;
     int32_t fine = c->max_iterations - coarse;
@@ -600,7 +620,7 @@ static result_t st_revaa(const ray_t *ray, sdf_fn sdf, const rmo_cfg *c)
         double lo = py_min(d, d_hi), hi = py_max(d, d_hi);
         if (lo <= 0.0 && hi >= 0.0) {
             double a = t, b = next_t;
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < c->revaa_bisection_steps; ++j) {
                 double mid = 0.5 * (a + b);
                 double dm = sdf(ray_at(ray, mid));
                 iterations += 1;

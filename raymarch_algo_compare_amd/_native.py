@@ -23,6 +23,7 @@ ERROR_NAMES = {0: "RM_OK", -1: "RM_E_BAD_SCENE", -2: "RM_E_BAD_STRATEGY", -3: "R
 
 EXPORTS = [
     "rm_init", "rm_shutdown", "rm_last_error", "rm_device_info", "rm_num_scenes", "rm_num_strategies",
+    "rm_default_strategy_params",
     "rm_sdf_eval", "rm_march_rays", "rm_march_rays_team", "rm_render", "rm_render_outputs", "rm_render_device", "rm_stats_device_bytes",
     "rm_read_stats", "rm_bench_device", "rm_alloc_frame", "rm_free_frame", "rm_copy_frame_to_host",
     "rm_bench_store_path", "rm_render_batch", "rm_render_batch_outputs", "rm_set_pass_timing", "rm_get_pass_ms", "rm_set_queue_capacity",
@@ -35,10 +36,55 @@ class RmError(RuntimeError):
         self.code = code
 
 
+# RmStrategyParams (include/rm_hip.h): the reference strategies' constructor arguments (relaxed_sphere.py:17,
+# auto_relaxed.py:21-23, slope_auto_relaxed.py:25, overstep_bisect.py:18, adaptive_hybrid.py:17-19) and four
+# literals of their march() bodies; (field, ctype, the reference's default).
+STRATEGY_PARAM_FIELDS = [
+    ("omega", ctypes.c_double, 1.2), ("ar_omega_min", ctypes.c_double, 1.0), ("ar_omega_max", ctypes.c_double, 2.0),
+    ("ar_smoothing", ctypes.c_double, 0.7), ("ar_growth_rate", ctypes.c_double, 1.05),
+    ("ar_decay_rate", ctypes.c_double, 0.7), ("beta", ctypes.c_double, 0.3),
+    ("overstep_min_step", ctypes.c_double, 0.01), ("hybrid_stuck_step_ratio", ctypes.c_double, 0.001),
+    ("hybrid_min_step", ctypes.c_double, 0.005), ("margin", ctypes.c_double, 0.05),
+    ("ar_omega_init", ctypes.c_double, 1.2),
+    ("overstep_bisection_steps", ctypes.c_int32, 16), ("hybrid_stuck_threshold", ctypes.c_int32, 5),
+    ("segment_bisection_steps", ctypes.c_int32, 8), ("revaa_bisection_steps", ctypes.c_int32, 8),
+]
+DEFAULT_STRATEGY_PARAMS = {n: d for n, _, d in STRATEGY_PARAM_FIELDS}
+
+
+class RmStrategyParams(ctypes.Structure):
+    _fields_ = [(n, t) for n, t, _ in STRATEGY_PARAM_FIELDS]
+
+
 class RmMarchConfig(ctypes.Structure):
     _fields_ = [("max_iterations", ctypes.c_int32), ("full", ctypes.c_int32),
                 ("hit_threshold", ctypes.c_double), ("max_distance", ctypes.c_double),
-                ("lipschitz", ctypes.c_double)]
+                ("lipschitz", ctypes.c_double), ("use_params", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("params", RmStrategyParams)]
+
+
+def fill_params(cfg: RmMarchConfig, params: dict | None) -> None:
+    """Set cfg.params from a dict of RmStrategyParams overrides ({} / None: the reference's defaults)."""
+    if not params:
+        cfg.use_params = 0
+        return
+    vals = dict(DEFAULT_STRATEGY_PARAMS)
+    for k, v in params.items():
+        if k not in vals:
+            raise KeyError(f"unknown strategy parameter {k!r} (RmStrategyParams has {sorted(vals)})")
+        vals[k] = v
+    for n, t, _ in STRATEGY_PARAM_FIELDS:
+        setattr(cfg.params, n, int(vals[n]) if t is ctypes.c_int32 else float(vals[n]))
+    cfg.use_params = 1
+
+
+def march_config(max_iterations=512, full=False, hit_threshold=1e-4, max_distance=100.0, lipschitz=1.0,
+                 params: dict | None = None) -> RmMarchConfig:
+    c = RmMarchConfig()
+    c.max_iterations, c.full = int(max_iterations), 1 if full else 0
+    c.hit_threshold, c.max_distance, c.lipschitz = float(hit_threshold), float(max_distance), float(lipschitz)
+    fill_params(c, params)
+    return c
 
 
 class RmFrameDesc(ctypes.Structure):
@@ -100,6 +146,8 @@ def load() -> ctypes.CDLL:
         L.rm_shutdown.restype = None
         L.rm_last_error.restype = ctypes.c_char_p
         L.rm_device_info.argtypes = [ctypes.POINTER(RmDeviceInfo)]
+        L.rm_default_strategy_params.argtypes = [ctypes.POINTER(RmStrategyParams)]
+        L.rm_default_strategy_params.restype = None
         L.rm_sdf_eval.argtypes = [ctypes.c_int, dp, ctypes.c_size_t, dp]
         L.rm_march_rays.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(RmMarchConfig), dp, dp,
                                     ctypes.c_size_t, vp, dp, vp, dp]
@@ -126,7 +174,7 @@ def load() -> ctypes.CDLL:
         L.rm_set_queue_capacity.argtypes = [ctypes.c_int64]
         L.rm_get_pass_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_float)]
         for name in EXPORTS:
-            if name not in ("rm_shutdown", "rm_last_error", "rm_stats_device_bytes"):
+            if name not in ("rm_shutdown", "rm_last_error", "rm_stats_device_bytes", "rm_default_strategy_params"):
                 getattr(L, name).restype = ctypes.c_int
         _lib = L
         return L
@@ -165,7 +213,7 @@ def device_info() -> dict:
 def make_desc(scene_id, strategy_id, cam14, width, height, row0=0, rows=None, max_iterations=512,
               hit_threshold=1e-4, max_distance=100.0, lipschitz=1.0, full=False, tile_rows=0, refill_min=0,
               grid_waves=0, band_rows=0, band_stride=0, band_offset=0, tile_order_mode=0, eval_mode=0,
-              suspend_after=(0, 0), resume_grid=0, resume_mode=0) -> RmFrameDesc:
+              suspend_after=(0, 0), resume_grid=0, resume_mode=0, params: dict | None = None) -> RmFrameDesc:
     d = RmFrameDesc()
     d.scene_id, d.strategy_id = int(scene_id), int(strategy_id)
     d.width, d.height = int(width), int(height)
@@ -181,6 +229,7 @@ def make_desc(scene_id, strategy_id, cam14, width, height, row0=0, rows=None, ma
     d.march.hit_threshold = float(hit_threshold)
     d.march.max_distance = float(max_distance)
     d.march.lipschitz = float(lipschitz)
+    fill_params(d.march, params)
     d.tile_rows, d.refill_min, d.grid_waves = int(tile_rows), int(refill_min), int(grid_waves)
     d.band_rows, d.band_stride, d.band_offset = int(band_rows), int(band_stride), int(band_offset)
     d.tile_order_mode = int(tile_order_mode)
@@ -257,9 +306,8 @@ def render_batch(shape: RmFrameDesc, cams, configs=None, want_evals=False) -> di
             if isinstance(c, RmMarchConfig):
                 cfg_arr[i] = c
             else:
-                cfg_arr[i] = RmMarchConfig(int(c.get("max_iterations", 512)), 1 if c.get("full") else 0,
-                                           float(c.get("hit_threshold", 1e-4)), float(c.get("max_distance", 100.0)),
-                                           float(c.get("lipschitz", 1.0)))
+                cfg_arr[i] = march_config(c.get("max_iterations", 512), c.get("full"), c.get("hit_threshold", 1e-4),
+                                          c.get("max_distance", 100.0), c.get("lipschitz", 1.0), c.get("params"))
     st = (RmStats * n)()
     ms = ctypes.c_float(0.0)
     out["evals"] = np.empty((n, rows, W), np.int32) if want_evals else None
@@ -282,12 +330,12 @@ def sdf_eval(scene_id: int, pts) -> np.ndarray:
 
 
 def march_rays(scene_id, strategy_id, origins, dirs, max_iterations=512, hit_threshold=1e-4, max_distance=100.0,
-               lipschitz=1.0, team=False):
+               lipschitz=1.0, team=False, params: dict | None = None):
     L = init()
     origins = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
     dirs = np.ascontiguousarray(dirs, dtype=np.float64).reshape(-1, 3)
     n = len(origins)
-    cfg = RmMarchConfig(int(max_iterations), 1, float(hit_threshold), float(max_distance), float(lipschitz))
+    cfg = march_config(max_iterations, True, hit_threshold, max_distance, lipschitz, params)
     hit, t = np.empty(n, np.uint8), np.empty(n, np.float64)
     iters, fs = np.empty(n, np.int32), np.empty(n, np.float64)
     dp = ctypes.POINTER(ctypes.c_double)

@@ -38,15 +38,20 @@ class HipCollector:
         desc = _native.make_desc(
             scene.id, strategy.id, camera.params14(), camera.width, camera.height, row0, rows,
             self.config.max_iterations, self.config.hit_threshold, self.config.max_distance,
-            self._lipschitz(strategy), self.full, **self.tuning)
+            self._lipschitz(strategy), self.full, params=strategy.params, **self.tuning)
         return _native.render(desc, want_t_raw=self.full, want_final_sdf=self.full, warmup=warmup,
                               repeats=repeats)
 
-    def benchmark_batch(self, strategy: StrategyInfo, scene: SceneInfo, cameras, configs=None, want_evals: bool = False):
+    def benchmark_batch(self, strategy: StrategyInfo, scene: SceneInfo, cameras, configs=None, want_evals: bool = False,
+                        params=None):
         """Render one frame per camera (optionally one MarchConfig per frame) in ONE launch
         (rm_render_batch) and return a RayMarchStats per frame -- the shape of the reference's sweeps
         over curated viewpoints and iteration-budget / epsilon levels (viewpoints.py:41-140,
-        sweep.py:96-127).  Cameras must share the resolution.  fp32 depth (the 9 B/ray path)."""
+        sweep.py:96-127).  Cameras must share the resolution.  fp32 depth (the 9 B/ray path).
+        `params`: optional list, one dict of RmStrategyParams overrides per frame (the reference's parameter grid,
+        param_grid.py:20-27 / sweep.py:181), applied on top of the strategy's own constructor arguments.
+        want_evals renders with march.full = 1 so the evals map counts every sdf() call the reference's march()
+        makes (its final_sdf evaluations included), like the single-frame goldens."""
         import numpy as np
         cameras = list(cameras)
         if not cameras:
@@ -55,13 +60,13 @@ class HipCollector:
         if any(c.width != w or c.height != h for c in cameras):
             raise ValueError("all cameras of a batch must share the resolution")
         _native.init(self.device_id)
-        cfgs = None
-        if configs is not None:
-            cfgs = [dict(max_iterations=c.max_iterations, hit_threshold=c.hit_threshold, max_distance=c.max_distance,
-                         lipschitz=self._lipschitz(strategy)) for c in configs]
-        else:
-            cfgs = [dict(max_iterations=self.config.max_iterations, hit_threshold=self.config.hit_threshold,
-                         max_distance=self.config.max_distance, lipschitz=self._lipschitz(strategy))] * len(cameras)
+        if params is not None and len(params) != len(cameras):
+            raise ValueError("one parameter dict per frame")
+        mcs = list(configs) if configs is not None else [self.config] * len(cameras)
+        cfgs = [dict(max_iterations=c.max_iterations, hit_threshold=c.hit_threshold, max_distance=c.max_distance,
+                     lipschitz=self._lipschitz(strategy), full=bool(want_evals),
+                     params=dict(strategy.params, **(params[i] if params is not None else {})))
+                for i, c in enumerate(mcs)]
         shape = _native.make_desc(scene.id, strategy.id, cameras[0].params14(), w, h, **self.tuning)
         start = time.perf_counter()
         out = _native.render_batch(shape, np.stack([c.params14() for c in cameras]), cfgs, want_evals=want_evals)

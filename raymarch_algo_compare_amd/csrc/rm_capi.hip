@@ -140,6 +140,11 @@ rm::MarchCfg to_cfg(const RmMarchConfig& m)
     c.lipschitz = m.lipschitz;
     c.max_iterations = m.max_iterations;
     c.full = m.full ? 1 : 0;
+    c.prm = rm::default_strat_params();
+    if (m.use_params) {
+        static_assert(sizeof(RmStrategyParams) == sizeof(rm::StratParams), "RmStrategyParams and rm::StratParams must match");
+        memcpy(&c.prm, &m.params, sizeof c.prm);
+    }
     return c;
 }
 
@@ -178,7 +183,7 @@ int make_args(const RmFrameDesc* d, float* depth, int32_t* iters, uint8_t* hit, 
         wgs = (d->grid_waves + rm::kWavesPerWG - 1) / rm::kWavesPerWG;
     } else {
         int per_cu = 0;
-        hipError_t e = rm::scene(d->scene_id)->occupancy(d->strategy_id, th, a->interleave, &per_cu);
+        hipError_t e = rm::scene(d->scene_id)->occupancy(d->strategy_id, th, a->interleave, 0, &per_cu);
         if (e != hipSuccess || per_cu <= 0) per_cu = 2;
         // three workgroups per CU at most: the cheap scenes fit four, and measured 10-16 % slower with
         // four (Sphere 0.50 -> 0.45 ms, Cube 0.40 -> 0.34) while the long-ray scenes are indifferent
@@ -494,6 +499,13 @@ extern "C" {
 const char* rm_last_error(void) { return g_err; }
 int rm_num_scenes(void) { return RM_NUM_SCENES; }
 int rm_num_strategies(void) { return RM_NUM_STRATEGIES; }
+
+void rm_default_strategy_params(RmStrategyParams* out)
+{
+    if (!out) return;
+    const rm::StratParams p = rm::default_strat_params();
+    memcpy(out, &p, sizeof *out);
+}
 size_t rm_stats_device_bytes(void) { return kStatsBytes; }
 
 int rm_init(int device_id)
@@ -776,7 +788,7 @@ int rm_render_batch_outputs(const RmFrameDesc* shape, int32_t nframes, const dou
     if (d.grid_waves <= 0) {      // the batch is one big launch: size the persistent grid for all its tiles
         const long long ntiles = (long long)a.tiles_per_frame * nframes;
         int per_cu = 0;
-        if (rm::scene(d.scene_id)->occupancy(d.strategy_id, tile_h, a.interleave, &per_cu) != hipSuccess || per_cu <= 0) per_cu = 2;
+        if (rm::scene(d.scene_id)->occupancy(d.strategy_id, tile_h, a.interleave, 1, &per_cu) != hipSuccess || per_cu <= 0) per_cu = 2;
         per_cu = std::min(per_cu, 3);
         grid = (int)std::max<long long>(1, std::min<long long>((long long)g.prop.multiProcessorCount * per_cu,
                                                                 (ntiles + rm::kWavesPerWG - 1) / rm::kWavesPerWG));

@@ -66,14 +66,52 @@ RM_HD vec3 normalized(vec3 a)                                                   
     return v3(a.x * inv, a.y * inv, a.z * inv);
 }
 
+// Constructor arguments of the reference's strategies (defaults in the comments) and four constants their
+// march() bodies hold as literals; RmStrategyParams of the C ABI (include/rm_hip.h), same order.
+struct StratParams {
+    double omega;                    // RelaxedSphereTracing(omega=1.2)              relaxed_sphere.py:17
+    double ar_omega_min;             // AutoRelaxedSphereTracing(omega_min=1.0,       auto_relaxed.py:21-23
+    double ar_omega_max;             //   omega_max=2.0,
+    double ar_smoothing;             //   smoothing=0.7,
+    double ar_growth_rate;           //   growth_rate=1.05,
+    double ar_decay_rate;            //   decay_rate=0.7)
+    double beta;                     // SlopeAutoRelaxed(beta=0.3)                   slope_auto_relaxed.py:25
+    double overstep_min_step;        // OverstepBisectTracing(min_step_factor=0.01,   overstep_bisect.py:18
+    double hybrid_stuck_step_ratio;  // AdaptiveHybridTracing(stuck_step_ratio=0.001, adaptive_hybrid.py:17-19
+    double hybrid_min_step;          //   min_step_factor=0.005,
+    double margin;                   // `margin = 0.05` in SkippingSpheresTracing.march   skipping_spheres.py:30
+    double ar_omega_init;            // `omega = 1.2` in AutoRelaxedSphereTracing.march   auto_relaxed.py:41
+    int32_t overstep_bisection_steps;   //   bisection_steps=16)                      overstep_bisect.py:18
+    int32_t hybrid_stuck_threshold;     //   stuck_threshold=5,                       adaptive_hybrid.py:17
+    int32_t segment_bisection_steps;    // `range(8)` in SegmentTracing.march         segment_tracing.py:79
+    int32_t revaa_bisection_steps;      // `range(8)` in RevAAApproxTracing.march     rev_affine.py:70
+};
+
+RM_HD StratParams default_strat_params()
+{
+    StratParams p;
+    p.omega = 1.2;
+    p.ar_omega_min = 1.0; p.ar_omega_max = 2.0; p.ar_smoothing = 0.7; p.ar_growth_rate = 1.05; p.ar_decay_rate = 0.7;
+    p.beta = 0.3;
+    p.overstep_min_step = 0.01;
+    p.hybrid_stuck_step_ratio = 0.001; p.hybrid_min_step = 0.005;
+    p.margin = 0.05;
+    p.ar_omega_init = 1.2;
+    p.overstep_bisection_steps = 16; p.hybrid_stuck_threshold = 5; p.segment_bisection_steps = 8; p.revaa_bisection_steps = 8;
+    return p;
+}
+
 // MarchConfig (config.py:19-29): only these three are read by the CPU strategies.
-// `lipschitz` is SegmentTracing.lipschitz as wired by main.py:58-61.
+// `lipschitz` is SegmentTracing.lipschitz as wired by main.py:58-61; `prm` the strategy's own constants.
+// A kernel that renders ONE frame reads this record from its arguments (scalar registers); a batch
+// kernel keeps the fields its strategy reads per lane (rm_kernels.h).
 struct MarchCfg {
     double hit_threshold;
     double max_distance;
     double lipschitz;
     int32_t max_iterations;
     int32_t full;  // 1: also produce final_sdf (costs the reference's tail evaluations)
+    StratParams prm;
 };
 
 }  // namespace rm

@@ -259,7 +259,12 @@ template <class Scene> struct EvalOf<Scene, true> { using type = typename Scene:
 // (strategy step) and begins its next evaluation while its neighbours are still iterating.  The
 // lanes of a wavefront rarely need the same trip count (Mandelbulb: 1..8, mean 1.8), so a whole
 // evaluation per turn leaves more than half of the lanes idle inside the SDF loop.
-template <class Scene, class Strat, int TILE_H, bool INTERLEAVE>
+//
+// BATCH: the launch renders a frame table (rm_render_batch) and every ray carries the march configuration of
+// its own frame in vector registers (only the fields its strategy reads survive).  A one-frame launch reads
+// the configuration -- thresholds and the strategy's constructor arguments -- from the kernel arguments, i.e.
+// from scalar registers.
+template <class Scene, class Strat, int TILE_H, bool INTERLEAVE, bool BATCH>
 __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelArgs a)
 {
     static_assert(!INTERLEAVE || SceneIterative<Scene>::value, "INTERLEAVE needs Scene::Eval");
@@ -297,8 +302,8 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
     uint32_t my_gi = 0;                           // ... and its element index in the output arrays
     int nev = 0;                                  // SDF evaluations this ray's march has performed
     vec3 origin = v3(0.0, 0.0, 0.0), dir = v3(0.0, 0.0, 0.0);
-    MarchCfg cfg;                                 // of the frame this lane's ray belongs to
-    cfg.hit_threshold = 0.0; cfg.max_distance = 0.0; cfg.lipschitz = 1.0; cfg.max_iterations = 0; cfg.full = a.full;
+    MarchCfg lane_cfg = a.single.cfg;             // BATCH: of the frame this lane's ray belongs to
+    const MarchCfg& cfg = BATCH ? lane_cfg : a.single.cfg;
     Strat s;
     typename EvalOf<Scene, INTERLEAVE>::type ev;  // INTERLEAVE: the SDF evaluation in flight
     bool ready = false;                           // INTERLEAVE: its value can be consumed
@@ -419,13 +424,14 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
                         my_slot = cur;
                         my_pix = py * kTileW + px;
                         my_gi = (uint32_t)(cg.out0 + (size_t)(cg.y0 + py) * (size_t)a.width + (size_t)(cg.x0 + px));
-                        FrameParams fp;                                   // wave-uniform: scalar loads either way
-                        if (a.frames) fp = a.frames[cg.frame]; else fp = a.single;
-                        camera_ray(fp.cam, a.width, a.height, cg.x0 + px, cg.gy0 + py, origin, dir);
-                        cfg.hit_threshold = fp.cfg.hit_threshold;
-                        cfg.max_distance = fp.cfg.max_distance;
-                        cfg.lipschitz = fp.cfg.lipschitz;
-                        cfg.max_iterations = fp.cfg.max_iterations;
+                        if constexpr (BATCH) {                            // cg.frame is wave-uniform: scalar loads
+                            const FrameParams& fp = a.frames[cg.frame];
+                            camera_ray(fp.cam, a.width, a.height, cg.x0 + px, cg.gy0 + py, origin, dir);
+                            lane_cfg = fp.cfg;
+                            lane_cfg.full = a.full;
+                        } else {
+                            camera_ray(a.single.cam, a.width, a.height, cg.x0 + px, cg.gy0 + py, origin, dir);
+                        }
                         nev = 0;
                         if (s.start(cfg)) {
                             s_depth[cur][my_pix] = s.res.hit ? (float)s.res.t : 0.0f;
@@ -525,7 +531,7 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
 // again for a last, sparse pass.  The march state between two SDF evaluations is the strategy
 // record, so a resumed ray continues bit-for-bit where it stopped.  Results go straight to the
 // output arrays (scattered 4 + 4 + 1 byte stores of a few per cent of the pixels).
-template <class Scene, class Strat, bool INTERLEAVE>
+template <class Scene, class Strat, bool INTERLEAVE, bool BATCH>
 __global__ __launch_bounds__(64 * kWavesPerWG) void resume_kernel(const KernelArgs a, const int level)
 {
     static_assert(!INTERLEAVE || SceneIterative<Scene>::value, "INTERLEAVE needs Scene::Eval");
@@ -550,8 +556,8 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void resume_kernel(const KernelAr
     uint32_t my_gi = 0;
     int nev = 0;
     vec3 origin = v3(0.0, 0.0, 0.0), dir = v3(0.0, 0.0, 0.0);
-    MarchCfg cfg;
-    cfg.hit_threshold = 0.0; cfg.max_distance = 0.0; cfg.lipschitz = 1.0; cfg.max_iterations = 0; cfg.full = a.full;
+    MarchCfg lane_cfg = a.single.cfg;             // BATCH: of the frame this lane's ray belongs to
+    const MarchCfg& cfg = BATCH ? lane_cfg : a.single.cfg;
     Strat s;
     typename EvalOf<Scene, INTERLEAVE>::type ev;
     bool ready = false;
@@ -582,13 +588,15 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void resume_kernel(const KernelAr
                     const int gy = a.band_rows > 0
                         ? a.row0 + ((y / a.band_rows) * a.band_stride + a.band_offset) * a.band_rows + (y % a.band_rows)
                         : a.row0 + y;
-                    FrameParams fp;
-                    if (a.frames) fp = a.frames[frame]; else fp = a.single;
-                    camera_ray(fp.cam, a.width, a.height, x, gy, origin, dir);   // recomputed: same bits as the first pass
-                    cfg.hit_threshold = fp.cfg.hit_threshold;
-                    cfg.max_distance = fp.cfg.max_distance;
-                    cfg.lipschitz = fp.cfg.lipschitz;
-                    cfg.max_iterations = fp.cfg.max_iterations;
+                    // the camera ray is recomputed: same bits as in the first pass
+                    if constexpr (BATCH) {
+                        const FrameParams& fp = a.frames[frame];
+                        camera_ray(fp.cam, a.width, a.height, x, gy, origin, dir);
+                        lane_cfg = fp.cfg;
+                        lane_cfg.full = a.full;
+                    } else {
+                        camera_ray(a.single.cam, a.width, a.height, x, gy, origin, dir);
+                    }
                     active = true;
                     if constexpr (INTERLEAVE) ready = Scene::begin(ev, origin + dir * s.te);
                 }
@@ -752,7 +760,7 @@ __global__ __launch_bounds__(64 * kTeam) void march_rays_team_kernel(MarchCfg cf
 // the same state and takes the same decisions, wave 0 owns the side effects (queue pops, stores, stats).
 // Whole evaluations per turn: the rays that reach this pass are long, near-surface rays whose
 // evaluations all take most of the 8 trips.
-template <class Scene, class Strat>
+template <class Scene, class Strat, bool BATCH>
 __global__ __launch_bounds__(64 * kTeam) void resume_team_kernel(const KernelArgs a, const int level)
 {
     using Entry = QEntry<Strat>;
@@ -776,8 +784,8 @@ __global__ __launch_bounds__(64 * kTeam) void resume_team_kernel(const KernelArg
     uint32_t my_gi = 0;
     int nev = 0;
     vec3 origin = v3(0.0, 0.0, 0.0), dir = v3(0.0, 0.0, 0.0);
-    MarchCfg cfg;
-    cfg.hit_threshold = 0.0; cfg.max_distance = 0.0; cfg.lipschitz = 1.0; cfg.max_iterations = 0; cfg.full = a.full;
+    MarchCfg lane_cfg = a.single.cfg;             // BATCH: of the frame this lane's ray belongs to
+    const MarchCfg& cfg = BATCH ? lane_cfg : a.single.cfg;
     Strat s;
     typename Scene::Eval ev;
     int turn = 0;
@@ -806,13 +814,14 @@ __global__ __launch_bounds__(64 * kTeam) void resume_team_kernel(const KernelArg
                     const int gy = a.band_rows > 0
                         ? a.row0 + ((y / a.band_rows) * a.band_stride + a.band_offset) * a.band_rows + (y % a.band_rows)
                         : a.row0 + y;
-                    FrameParams fp;
-                    if (a.frames) fp = a.frames[frame]; else fp = a.single;
-                    camera_ray(fp.cam, a.width, a.height, x, gy, origin, dir);
-                    cfg.hit_threshold = fp.cfg.hit_threshold;
-                    cfg.max_distance = fp.cfg.max_distance;
-                    cfg.lipschitz = fp.cfg.lipschitz;
-                    cfg.max_iterations = fp.cfg.max_iterations;
+                    if constexpr (BATCH) {
+                        const FrameParams& fp = a.frames[frame];
+                        camera_ray(fp.cam, a.width, a.height, x, gy, origin, dir);
+                        lane_cfg = fp.cfg;
+                        lane_cfg.full = a.full;
+                    } else {
+                        camera_ray(a.single.cam, a.width, a.height, x, gy, origin, dir);
+                    }
                     active = true;
                 }
             }
@@ -889,7 +898,7 @@ struct SceneLaunchers {
     hipError_t (*resume)(int strategy, int level, const KernelArgs& a, int grid, hipStream_t s);
     hipError_t (*resume_team)(int strategy, int level, const KernelArgs& a, int grid, hipStream_t s);   // nullptr: no team form
     int (*entry_bytes)(int strategy);   // sizeof(QEntry<Strat>)
-    hipError_t (*occupancy)(int strategy, int tile_h, int interleave, int* blocks_per_cu);
+    hipError_t (*occupancy)(int strategy, int tile_h, int interleave, int batch, int* blocks_per_cu);
     hipError_t (*sdf_eval)(const double* xyz, size_t n, double* out, hipStream_t s);
     hipError_t (*march_rays)(int strategy, const MarchCfg& cfg, const double* o, const double* d, size_t n,
                              uint8_t* hit, double* t, int32_t* iters, double* fs, hipStream_t s);

@@ -20,29 +20,41 @@ constexpr bool kIter = SceneIterative<SceneT>::value;
 template <class Strat, int TH>
 static hipError_t launch_render(const KernelArgs& a, int grid, hipStream_t s)
 {
-    if (kIter && a.interleave)
-        hipLaunchKernelGGL((render_kernel<SceneT, Strat, TH, kIter>), dim3(grid), dim3(64 * kWavesPerWG), 0, s, a);
-    else
-        hipLaunchKernelGGL((render_kernel<SceneT, Strat, TH, false>), dim3(grid), dim3(64 * kWavesPerWG), 0, s, a);
+    const bool il = kIter && a.interleave;
+    if (a.frames) {
+        if (il) hipLaunchKernelGGL((render_kernel<SceneT, Strat, TH, kIter, true>), dim3(grid), dim3(64 * kWavesPerWG), 0, s, a);
+        else hipLaunchKernelGGL((render_kernel<SceneT, Strat, TH, false, true>), dim3(grid), dim3(64 * kWavesPerWG), 0, s, a);
+    } else {
+        if (il) hipLaunchKernelGGL((render_kernel<SceneT, Strat, TH, kIter, false>), dim3(grid), dim3(64 * kWavesPerWG), 0, s, a);
+        else hipLaunchKernelGGL((render_kernel<SceneT, Strat, TH, false, false>), dim3(grid), dim3(64 * kWavesPerWG), 0, s, a);
+    }
     return hipGetLastError();
 }
 
 template <class Strat>
 static hipError_t launch_resume(int level, const KernelArgs& a, int grid, hipStream_t s)
 {
-    if (kIter && a.interleave)
-        hipLaunchKernelGGL((resume_kernel<SceneT, Strat, kIter>), dim3(grid), dim3(64 * kWavesPerWG), 0, s, a, level);
-    else
-        hipLaunchKernelGGL((resume_kernel<SceneT, Strat, false>), dim3(grid), dim3(64 * kWavesPerWG), 0, s, a, level);
+    const bool il = kIter && a.interleave;
+    if (a.frames) {
+        if (il) hipLaunchKernelGGL((resume_kernel<SceneT, Strat, kIter, true>), dim3(grid), dim3(64 * kWavesPerWG), 0, s, a, level);
+        else hipLaunchKernelGGL((resume_kernel<SceneT, Strat, false, true>), dim3(grid), dim3(64 * kWavesPerWG), 0, s, a, level);
+    } else {
+        if (il) hipLaunchKernelGGL((resume_kernel<SceneT, Strat, kIter, false>), dim3(grid), dim3(64 * kWavesPerWG), 0, s, a, level);
+        else hipLaunchKernelGGL((resume_kernel<SceneT, Strat, false, false>), dim3(grid), dim3(64 * kWavesPerWG), 0, s, a, level);
+    }
     return hipGetLastError();
 }
 
 template <class Strat, int TH>
-static hipError_t occ_render(int interleave, int* blocks)
+static hipError_t occ_render(int interleave, int batch, int* blocks)
 {
-    if (kIter && interleave)
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, render_kernel<SceneT, Strat, TH, kIter>, 64 * kWavesPerWG, 0);
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, render_kernel<SceneT, Strat, TH, false>, 64 * kWavesPerWG, 0);
+    const bool il = kIter && interleave;
+    if (batch) {
+        if (il) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, render_kernel<SceneT, Strat, TH, kIter, true>, 64 * kWavesPerWG, 0);
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, render_kernel<SceneT, Strat, TH, false, true>, 64 * kWavesPerWG, 0);
+    }
+    if (il) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, render_kernel<SceneT, Strat, TH, kIter, false>, 64 * kWavesPerWG, 0);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, render_kernel<SceneT, Strat, TH, false, false>, 64 * kWavesPerWG, 0);
 }
 
 static hipError_t render(int strategy, int tile_h, const KernelArgs& a, int grid, hipStream_t s)
@@ -74,7 +86,8 @@ static hipError_t resume_team_impl(int strategy, int level, const KernelArgs& a,
         switch (strategy) {
 #define RM_X(id, S)                                                                                              \
     case id:                                                                                                     \
-        hipLaunchKernelGGL((resume_team_kernel<SceneT, S>), dim3(grid), dim3(64 * kTeam), 0, s, a, level);        \
+        if (a.frames) hipLaunchKernelGGL((resume_team_kernel<SceneT, S, true>), dim3(grid), dim3(64 * kTeam), 0, s, a, level);   \
+        else hipLaunchKernelGGL((resume_team_kernel<SceneT, S, false>), dim3(grid), dim3(64 * kTeam), 0, s, a, level);           \
         return hipGetLastError();
             RM_STRATEGY_LIST(RM_X)
 #undef RM_X
@@ -94,11 +107,11 @@ static int entry_bytes(int strategy)
     return 0;
 }
 
-static hipError_t occupancy(int strategy, int tile_h, int interleave, int* blocks)
+static hipError_t occupancy(int strategy, int tile_h, int interleave, int batch, int* blocks)
 {
     switch (strategy) {
 #define RM_X(id, S) \
-    case id: return occ_render<S, 4>(interleave, blocks);
+    case id: return occ_render<S, 4>(interleave, batch, blocks);
         RM_STRATEGY_LIST(RM_X)
 #undef RM_X
     }

@@ -89,10 +89,10 @@ struct StratStandard : StratBase {
     }
 };
 
-// 1: strategies/relaxed_sphere.py:28-70 (omega = 1.2)
+// 1: strategies/relaxed_sphere.py:28-70 (omega: constructor argument, :17)
 struct StratRelaxed : StratBase {
     double prev_d, omega;
-    RM_HD bool start(const MarchCfg& c) { prev_d = 0.0; omega = 1.2; return begin_loop(c); }
+    RM_HD bool start(const MarchCfg& c) { prev_d = 0.0; omega = c.prm.omega; return begin_loop(c); }
     RM_HD bool step(double d, const MarchCfg& c)
     {
         if (phase == PH_TAIL) { res.final_sdf = d; return true; }
@@ -111,17 +111,18 @@ struct StratRelaxed : StratBase {
     }
 };
 
-// 2: strategies/auto_relaxed.py:38-90
+// 2: strategies/auto_relaxed.py:38-90 (five constructor arguments, :21-23)
 struct StratAutoRelaxed : StratBase {
     double prev_d, omega, ema;
     RM_HD bool start(const MarchCfg& c)
     {
-        omega = 1.2; prev_d = __builtin_inf(); ema = 1.0;
+        omega = c.prm.ar_omega_init; prev_d = __builtin_inf(); ema = 1.0;
         return begin_loop(c);
     }
     RM_HD bool step(double d, const MarchCfg& c)
     {
-        const double omega_min = 1.0, omega_max = 2.0, smoothing = 0.7, growth = 1.05, decay = 0.7;
+        const double omega_min = c.prm.ar_omega_min, omega_max = c.prm.ar_omega_max, smoothing = c.prm.ar_smoothing,
+                     growth = c.prm.ar_growth_rate, decay = c.prm.ar_decay_rate;
         if (phase == PH_TAIL) { res.final_sdf = d; return true; }
         it = i + 1;
         if (rm_fabs(d) < c.hit_threshold) return finish(1, t, d);
@@ -143,7 +144,7 @@ struct StratAutoRelaxed : StratBase {
     }
 };
 
-// 3: strategies/slope_auto_relaxed.py:41-115 (beta = 0.3)
+// 3: strategies/slope_auto_relaxed.py:41-115 (beta: constructor argument, :25)
 struct StratSlope : StratBase {
     double r, z, m;
     RM_HD bool loop_head(const MarchCfg& c)
@@ -163,7 +164,7 @@ struct StratSlope : StratBase {
     }
     RM_HD bool step(double d, const MarchCfg& c)
     {
-        const double beta = 0.3;
+        const double beta = c.prm.beta;
         if (phase == PH_MAIN) {
             r = d; z = r; m = -1.0;
             return loop_head(c);
@@ -258,28 +259,28 @@ struct StratCurvature : StratBase {
     }
 };
 
-// 6: strategies/overstep_bisect.py:30-121 (min_step 0.01, 16 bisection steps)
+// 6: strategies/overstep_bisect.py:30-121 (min_step_factor, bisection_steps: constructor arguments, :18)
 struct StratOverstepBisect : StratBase {
     double t_near, t_far, t_mid;
     int32_t j;
-    RM_HD bool bis_head()
+    RM_HD bool bis_head(const MarchCfg& c)
     {
         t_mid = (t_near + t_far) * 0.5;
         te = t_mid;
-        if (j >= 16) { phase = PH_B; return false; }   // :104-112 final midpoint decides the hit
+        if (j >= c.prm.overstep_bisection_steps) { phase = PH_B; return false; }   // :104-112 final midpoint decides the hit
         it += 1;
         phase = PH_A;
         return false;
     }
     RM_HD bool after_phase1(const MarchCfg& c)
     {
-        if (t_far > 0.0) { j = 0; return bis_head(); }
+        if (t_far > 0.0) { j = 0; return bis_head(c); }
         return finish_miss(c);
     }
     RM_HD bool start(const MarchCfg& c)
     {
         t = 0.0; i = 0; it = 0; t_near = 0.0; t_far = -1.0; j = 0; t_mid = 0.0;
-        if (c.max_iterations - 16 <= 0) return after_phase1(c);
+        if (c.max_iterations - c.prm.overstep_bisection_steps <= 0) return after_phase1(c);
         te = t; phase = PH_MAIN;
         return false;
     }
@@ -291,14 +292,14 @@ struct StratOverstepBisect : StratBase {
             if (rm_fabs(d) < c.hit_threshold) return finish(1, t, d);
             if (d > 0.0) {
                 t_near = t;
-                t += py_max(d, 0.01);
+                t += py_max(d, c.prm.overstep_min_step);
             } else {
                 t_far = t;
                 return after_phase1(c);
             }
             if (t > c.max_distance) return finish_miss(c);
             ++i;
-            if (i >= c.max_iterations - 16) return after_phase1(c);
+            if (i >= c.max_iterations - c.prm.overstep_bisection_steps) return after_phase1(c);
             te = t;
             return false;
         }
@@ -310,14 +311,14 @@ struct StratOverstepBisect : StratBase {
                 return finish_hit_reeval(t_mid, c);
             }
             ++j;
-            return bis_head();
+            return bis_head(c);
         }
         // PH_B
         return finish(rm_fabs(d) < c.hit_threshold * 10.0, t_mid, d);
     }
 };
 
-// 7: strategies/skipping_spheres.py:25-72
+// 7: strategies/skipping_spheres.py:25-72 (margin: a literal there, :30; a uniform of the GLSL seam)
 struct StratSkipping : StratBase {
     int32_t j, coarse, fine;
     RM_HD bool fine_head(const MarchCfg& c)
@@ -341,7 +342,7 @@ struct StratSkipping : StratBase {
         if (phase == PH_TAIL) { res.final_sdf = d_raw; return true; }
         if (phase == PH_MAIN) {
             it = i + 1;
-            double d = d_raw - 0.05;
+            double d = d_raw - c.prm.margin;
             if (d < c.hit_threshold) return fine_head(c);
             t += d;
             if (t > c.max_distance) return fine_head(c);
@@ -371,7 +372,7 @@ struct StratRevAA : StratBase {
     RM_HD bool bis_head(const MarchCfg& c)
     {
         mid = 0.5 * (a + b);
-        if (j >= 8) return finish_hit_reeval(mid, c);
+        if (j >= c.prm.revaa_bisection_steps) return finish_hit_reeval(mid, c);
         te = mid; phase = PH_B;
         return false;
     }
@@ -410,7 +411,7 @@ struct StratRevAA : StratBase {
     }
 };
 
-// 9: strategies/adaptive_hybrid.py:35-149 (stuck 5 / 0.001, min_step 0.005)
+// 9: strategies/adaptive_hybrid.py:35-149 (stuck_threshold, stuck_step_ratio, min_step_factor: constructor arguments, :17-19)
 struct StratHybrid : StratBase {
     double t_near, t_far, t_mid;
     int32_t mode, small_cnt;   // mode 0 sphere, 1 overstep, 2 bisect
@@ -426,8 +427,8 @@ struct StratHybrid : StratBase {
             it = i + 1;
             if (rm_fabs(d) < c.hit_threshold) return finish(1, t, d);
             if (mode == 0) {
-                if (d > 0.0 && d < 0.001 * py_max(t, 1.0)) small_cnt += 1; else small_cnt = 0;
-                if (small_cnt >= 5) {
+                if (d > 0.0 && d < c.prm.hybrid_stuck_step_ratio * py_max(t, 1.0)) small_cnt += 1; else small_cnt = 0;
+                if (small_cnt >= c.prm.hybrid_stuck_threshold) {
                     mode = 1; t_near = t; t_far = -1.0; small_cnt = 0;
                     return next_iter(c);
                 }
@@ -439,7 +440,7 @@ struct StratHybrid : StratBase {
             } else if (mode == 1) {
                 if (d > 0.0) {
                     t_near = t;
-                    t += py_max(d, 0.005);
+                    t += py_max(d, c.prm.hybrid_min_step);
                 } else {
                     t_far = t; mode = 2;
                     return next_iter(c);
@@ -471,7 +472,7 @@ struct StratSegment : StratBase {
     int32_t k;
     RM_HD bool bis_head(const MarchCfg& c)
     {
-        if (k >= 8) {
+        if (k >= c.prm.segment_bisection_steps) {
             t = (t_lo + t_hi) * 0.5;
             return finish_hit_reeval(t, c);
         }

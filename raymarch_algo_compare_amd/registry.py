@@ -8,8 +8,8 @@ these records only carry what the host needs: names, categories, suggested camer
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
-from typing import List, Optional
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
 
 from .config import RenderConfig
 
@@ -41,6 +41,8 @@ class StrategyInfo:
     name: str         # MarchStrategy.name
     has_lipschitz: bool = False
     lipschitz: float = 1.0
+    # RmStrategyParams overrides (include/rm_hip.h) this instance was constructed with; {} = the reference's defaults
+    params: Dict[str, float] = field(default_factory=dict)
 
 
 SCENES: List[SceneInfo] = [
@@ -104,9 +106,48 @@ GRADED_STRATEGY_KEYS = ["Standard", "Relaxed", "Heuristic-Auto-Relaxed", "Slope-
 GRADED_SCENE_IDS = list(range(14))
 
 
-def _make_strategy(i: int) -> StrategyInfo:
+# Constructor keywords of the reference's strategy classes -> RmStrategyParams fields (relaxed_sphere.py:17,
+# auto_relaxed.py:21-23, slope_auto_relaxed.py:25, overstep_bisect.py:18, adaptive_hybrid.py:17-19,
+# segment_tracing.py:26).  None = accepted and not read by march() (as in the reference).
+CTOR_ARGS = {
+    "Relaxed": {"omega": "omega"},
+    "Heuristic-Auto-Relaxed": {"omega_min": "ar_omega_min", "omega_max": "ar_omega_max", "smoothing": "ar_smoothing",
+                               "growth_rate": "ar_growth_rate", "decay_rate": "ar_decay_rate"},
+    "Slope-Auto-Relaxed": {"beta": "beta"},
+    "Overstep-Bisect": {"min_step_factor": "overstep_min_step", "bisection_steps": "overstep_bisection_steps"},
+    "Adaptive-Hybrid": {"stuck_threshold": "hybrid_stuck_threshold", "stuck_step_ratio": "hybrid_stuck_step_ratio",
+                        "min_step_factor": "hybrid_min_step", "bisection_steps": None, "fallback_to_segment_after": None},
+    "Segment": {"lipschitz": "lipschitz"},
+}
+# constants the CPU strategies hold as literals, tunable here by their RmStrategyParams name
+LITERAL_ARGS = {"Skipping-Spheres": ("margin",), "Heuristic-Auto-Relaxed": ("ar_omega_init",),
+                "Segment": ("segment_bisection_steps",), "RevAA": ("revaa_bisection_steps",)}
+
+
+def _make_strategy(i: int, **ctor) -> StrategyInfo:
+    """`STRATEGIES[key](**ctor)` of the reference: the constructor's own keyword names (plus this engine's names for
+    the literals).  short_name / name follow the instance like the reference's f-strings do."""
     key, short, name, has_l = _STRATEGY_ROWS[i]
-    return StrategyInfo(i, key, short, name, has_l)
+    st = StrategyInfo(i, key, short, name, has_l)
+    known = CTOR_ARGS.get(key, {})
+    for k, v in ctor.items():
+        if k in known:
+            if known[k] == "lipschitz":
+                st.lipschitz = float(v)
+            elif known[k] is not None:
+                st.params[known[k]] = v
+        elif k in LITERAL_ARGS.get(key, ()):
+            st.params[k] = v
+        else:
+            raise TypeError(f"{key}: unexpected constructor argument {k!r} (accepted: "
+                            f"{sorted(known) + list(LITERAL_ARGS.get(key, ()))})")
+    if key == "Relaxed" and "omega" in st.params:                  # relaxed_sphere.py:22,26
+        w = st.params["omega"]
+        st.short_name, st.name = f"Relaxed(ω={w})", f"Relaxed Sphere Tracing (ω={w})"
+    if key == "Slope-Auto-Relaxed" and "beta" in st.params:         # slope_auto_relaxed.py:35,39
+        b = st.params["beta"]
+        st.short_name, st.name = f"Slope-AR(β={b})", f"Slope-Based Auto-Relaxed (β={b})"
+    return st
 
 
 def get_all_scenes() -> List[SceneInfo]:
@@ -126,21 +167,22 @@ def get_scene_by_name(name: str) -> Optional[SceneInfo]:
     return None
 
 
-def get_strategy_by_name(name: str) -> Optional[StrategyInfo]:
+def get_strategy_by_name(name: str, **ctor) -> Optional[StrategyInfo]:
     """Reference lookup rule (strategies/__init__.py:31-45): case-insensitive exact match on the
     registry KEYS, then substring.  A fresh record per call, like the reference's `strat_class()`.
     Extension: an exact short_name ("AR-ST", "Hybrid", "Slope-AR(β=0.3)") is also accepted,
-    tried after the reference's two rules so reference-valid names resolve identically."""
+    tried after the reference's two rules so reference-valid names resolve identically.
+    `ctor`: constructor arguments of the reference class (e.g. omega=1.6, min_step_factor=0.02), see CTOR_ARGS."""
     low = name.lower()
     for i, row in enumerate(_STRATEGY_ROWS):
         if row[0].lower() == low:
-            return _make_strategy(i)
+            return _make_strategy(i, **ctor)
     for i, row in enumerate(_STRATEGY_ROWS):
         if low in row[0].lower():
-            return _make_strategy(i)
+            return _make_strategy(i, **ctor)
     for i, row in enumerate(_STRATEGY_ROWS):
         if row[1].lower() == low:
-            return _make_strategy(i)
+            return _make_strategy(i, **ctor)
     return None
 
 

@@ -33,7 +33,7 @@ def run_gpu_benchmark(scene_name: str, strategy_name: str, render_cfg: RenderCon
     _native.init(device_id)
     desc = _native.make_desc(scene.id, strategy.id, cam.params14(), cam.width, cam.height, 0, None,
                              march_cfg.max_iterations, march_cfg.hit_threshold, march_cfg.max_distance,
-                             strategy.lipschitz if strategy.has_lipschitz else 1.0, True)
+                             strategy.lipschitz if strategy.has_lipschitz else 1.0, True, params=strategy.params)
     repeats = max(1, min(int(gpu_repeats), _native.RM_MAX_TIMED))
     out = _native.render(desc, want_t_raw=True, want_final_sdf=True, warmup=max(0, int(gpu_warmup)), repeats=repeats)
     times = [ms * 1e-3 for ms in out["timing"]["ms_each"]]
@@ -64,8 +64,14 @@ def run_gpu_benchmark(scene_name: str, strategy_name: str, render_cfg: RenderCon
 # strategy ids of the reference's fragment shader (main.glsl:64-74) -> registry keys of this engine
 GLSL_STRATEGY_KEYS = {0: "Standard", 1: "Overstep-Bisect", 2: "Relaxed", 3: "Segment", 4: "Enhanced",
                       5: "Heuristic-Auto-Relaxed", 6: "Skipping-Spheres", 7: "RevAA"}
-# uniforms the shader takes per run (runner.py:112-127) and the values the CPU-path strategies are built with
-_PARAM_DEFAULTS = {"omega": 1.2, "kappa": 2.0, "beta": 0.3, "margin": 0.05, "stepScale": 1.0}
+# Uniforms the shader takes per run (gpu/runner.py:108-124) -> RmStrategyParams fields of the CPU-path strategies
+# that read the same constant: `omega` is RelaxedSphereTracing's constructor argument and the start value of
+# AutoRelaxedSphereTracing's omega (the shader's two relaxed marchers share the uniform, param_grid.py:21-23),
+# `beta` SlopeAutoRelaxed's, `margin` the fattening of Skipping-Spheres.
+SHADER_UNIFORMS = {"omega": ("omega", "ar_omega_init"), "beta": ("beta",), "margin": ("margin",)}
+# uniforms that exist only in the GLSL marcher bodies (segment growth, understepping): the CPU-path strategies have
+# no such constant, so only their defaults can be honoured
+_GLSL_ONLY_DEFAULTS = {"kappa": 2.0, "stepScale": 1.0}
 
 
 class GPURunner:
@@ -75,8 +81,10 @@ class GPURunner:
     Deliberate differences: fp64 and the CPU camera model (the shader's pinhole ignores
     fov), the catalogue SDFs, rows top-to-bottom in both calls, `strategy_id` follows the shader's numbering
     (GLSL_STRATEGY_KEYS; 8 = Safe-Relaxed and 9 = Dense-March exist only in GLSL and raise ValueError; pass
-    `strategy_key=` for this engine's other strategies), and `params` may only restate the defaults -- the
-    strategies' tuning constants are compiled in, as the registry builds them (`minStep` is GLSL-only, ignored)."""
+    `strategy_key=` for this engine's other strategies).  `params` takes the shader's uniform names like the
+    reference seam (gpu/runner.py:120-124): omega / beta / margin reach the CPU-path strategies' constants through
+    RmStrategyParams (SHADER_UNIFORMS); RmStrategyParams field names are accepted as they are; kappa / stepScale
+    exist only in the GLSL bodies (non-default values raise NotImplementedError) and `minStep` is ignored."""
 
     def __init__(self, device_id: int | None = None):
         self.device_id = device_id
@@ -93,16 +101,26 @@ class GPURunner:
         return st
 
     @staticmethod
-    def _check_params(params):
+    def strategy_params(params) -> dict:
+        """Shader uniform overrides (or RmStrategyParams names) -> RmStrategyParams overrides."""
+        out = {}
         for k, v in (params or {}).items():
             if k == "minStep":
                 continue
-            if k not in _PARAM_DEFAULTS:
+            if k in SHADER_UNIFORMS:
+                for f in SHADER_UNIFORMS[k]:
+                    out[f] = float(v)
+            elif k in _native.DEFAULT_STRATEGY_PARAMS:
+                out[k] = v
+            elif k in _GLSL_ONLY_DEFAULTS:
+                if float(v) != _GLSL_ONLY_DEFAULTS[k]:
+                    raise NotImplementedError(f"{k}={v}: a constant of the GLSL marchers only; the CPU-path strategies "
+                                              f"have no counterpart ({k}={_GLSL_ONLY_DEFAULTS[k]} is the shader default)")
+            else:
                 raise KeyError(f"unknown shader parameter {k!r}")
-            if float(v) != _PARAM_DEFAULTS[k]:
-                raise NotImplementedError(f"{k}={v}: the strategies' constants are compiled in ({k}={_PARAM_DEFAULTS[k]})")
+        return out
 
-    def _frame(self, scene_id, strategy, render_cfg, march_cfg, lipschitz, timed, want_evals):
+    def _frame(self, scene_id, strategy, render_cfg, march_cfg, lipschitz, timed, want_evals, params=None):
         if not 0 <= int(scene_id) < len(SCENES):
             raise ValueError(f"scene id {scene_id} out of range")
         cam = Camera(render_cfg.camera_position, render_cfg.camera_target, render_cfg.camera_up,
@@ -110,7 +128,8 @@ class GPURunner:
         _native.init(self.device_id)
         lip = float(lipschitz if lipschitz is not None else 1.0) if strategy.has_lipschitz else 1.0
         desc = _native.make_desc(int(scene_id), strategy.id, cam.params14(), cam.width, cam.height, 0, None,
-                                 march_cfg.max_iterations, march_cfg.hit_threshold, march_cfg.max_distance, lip, True)
+                                 march_cfg.max_iterations, march_cfg.hit_threshold, march_cfg.max_distance, lip, True,
+                                 params=dict(strategy.params, **self.strategy_params(params)))
         out = _native.render(desc, want_t_raw=True, want_final_sdf=True, repeats=1 if timed else 0, want_evals=want_evals)
         return cam, out
 
@@ -127,8 +146,7 @@ class GPURunner:
     def render(self, scene_id: int, strategy_id: int, render_cfg: RenderConfig, march_cfg: MarchConfig,
                lipschitz: float = 1.0, params: dict | None = None, *, strategy_key: str | None = None):
         """-> (pixels (H, W, 4) float32 [hit, iterations / max, t / max_distance, final_sdf], seconds)."""
-        self._check_params(params)
-        _, out = self._frame(scene_id, self._strategy(strategy_id, strategy_key), render_cfg, march_cfg, lipschitz, True, False)
+        _, out = self._frame(scene_id, self._strategy(strategy_id, strategy_key), render_cfg, march_cfg, lipschitz, True, False, params)
         return self._geom(out, march_cfg), out["timing"]["ms_median"] * 1e-3
 
     def capture(self, scene_id: int, strategy_id: int, render_cfg: RenderConfig, march_cfg: MarchConfig,
@@ -137,8 +155,7 @@ class GPURunner:
         targets of main.glsl:79-110: tetrahedron normals from four SDF evaluations (rm_sdf_eval) at the hit point,
         the shader's fixed key light + hemisphere ambient + gamma, its background on misses, and the number of SDF
         evaluations the march itself performed."""
-        self._check_params(params)
-        cam, out = self._frame(scene_id, self._strategy(strategy_id, strategy_key), render_cfg, march_cfg, lipschitz, False, True)
+        cam, out = self._frame(scene_id, self._strategy(strategy_id, strategy_key), render_cfg, march_cfg, lipschitz, False, True, params)
         h, w = out["iters"].shape
         hit = out["hit"] > 0
         c = cam.params14()

@@ -36,7 +36,32 @@ from .viewpoints import viewpoints_for
 DEFAULT_BUDGETS = [32, 64, 128, 256, 512]                       # reference sweep.py:48
 DEFAULT_EPSILONS = [1e-2, 3e-3, 1e-3, 3e-4, 1e-4, 3e-5, 1e-5]   # reference sweep.py:54
 
-ROW_FIELDS = ["scene", "strategy", "viewpoint", "category", "sweep_axis", "level", "max_iterations", "hit_threshold",
+# The reference's per-strategy parameter grid (param_grid.py:20-27: shader uniform -> values, first = default), by
+# registry key, for the strategies whose CPU-path arithmetic reads that constant (its Segment `kappa` and
+# Safe-Relaxed rows are GLSL-only marchers).  Uniform names are mapped by runner.SHADER_UNIFORMS.
+STRATEGY_PARAM_GRID = {
+    "Relaxed": {"omega": [1.2, 1.4, 1.6, 1.8]},
+    "Heuristic-Auto-Relaxed": {"omega": [1.2, 1.4, 1.6, 1.8]},
+    "Skipping-Spheres": {"margin": [0.02, 0.05, 0.1, 0.2]},
+}
+
+
+def param_combos(strategy_key: str):
+    """Each override dict of a strategy's grid (cartesian product); one empty dict without tunables (param_grid.py:30-40)."""
+    import itertools
+    grid = STRATEGY_PARAM_GRID.get(strategy_key)
+    if not grid:
+        return [{}]
+    keys = list(grid)
+    return [dict(zip(keys, vals)) for vals in itertools.product(*(grid[k] for k in keys))]
+
+
+def param_label(params: Dict) -> str:
+    """Stable short label of a combo (param_grid.py:43-48)."""
+    return "default" if not params else ",".join(f"{k}={v:g}" for k, v in sorted(params.items()))
+
+
+ROW_FIELDS = ["scene", "strategy", "params", "viewpoint", "category", "sweep_axis", "level", "max_iterations", "hit_threshold",
               "width", "height", "iters_mean", "iters_median", "iters_p95", "iters_max", "evals_mean", "evals_median", "evals_p95", "evals_max",
               "divergence_proxy", "hit_rate",
               "depth_mae_vs_finest", "hit_flips_vs_finest", "ms_per_frame"]
@@ -69,25 +94,31 @@ def finest_index(mode: str, levels) -> int:
     return int(np.argmax(vals)) if mode == "budget" else int(np.argmin(vals))
 
 
-def sweep_cell(collector: HipCollector, scene, strategy, mode: str, levels, width: int, height: int) -> List[Dict]:
-    """All viewpoints x levels of one (scene, strategy) in one batched launch -> one row per frame."""
+def sweep_cell(collector: HipCollector, scene, strategy, mode: str, levels, width: int, height: int, grid: bool = False) -> List[Dict]:
+    """All viewpoints x parameter combos x levels of one (scene, strategy) in one batched launch -> one row per
+    frame.  `grid` brute-forces the strategy's tunable parameters (reference sweep.py:181,222-223)."""
+    from .runner import GPURunner
     vps = viewpoints_for(scene)
-    cams, cfgs, tags = [], [], []
+    combos = param_combos(strategy.key) if grid else [{}]
+    cams, cfgs, prms, tags = [], [], [], []
     for vp in vps:
         cam = Camera(vp.position, vp.target, vp.up, 60.0, width, height)
-        for li, (value, mc, extra) in enumerate(levels):
-            cams.append(cam)
-            cfgs.append(mc)
-            tags.append((vp, li, value, extra))
-    frames = collector.benchmark_batch(strategy, scene, cams, cfgs, want_evals=True)
+        for combo in combos:
+            for li, (value, mc, extra) in enumerate(levels):
+                cams.append(cam)
+                cfgs.append(mc)
+                prms.append(GPURunner.strategy_params(combo))
+                tags.append((vp, li, value, extra, combo))
+    frames = collector.benchmark_batch(strategy, scene, cams, cfgs, want_evals=True, params=prms)
     fin = finest_index(mode, levels)
     rows = []
-    for i, ((vp, li, value, extra), st) in enumerate(zip(tags, frames)):
-        ref = frames[i - li + fin]                     # finest level of the same viewpoint
+    for i, ((vp, li, value, extra, combo), st) in enumerate(zip(tags, frames)):
+        ref = frames[i - li + fin]                     # finest level of the same viewpoint and parameter combo
         both = st.hit_map & ref.hit_map
         it = st.iteration_heatmap
         rows.append({
-            "scene": scene.name, "strategy": strategy.short_name, "viewpoint": vp.name, "category": vp.category,
+            "scene": scene.name, "strategy": strategy.short_name, "params": param_label(combo), "viewpoint": vp.name,
+            "category": vp.category,
             "sweep_axis": extra["sweep_axis"], "level": value, "max_iterations": extra["max_iterations"],
             "hit_threshold": extra["hit_threshold"], "width": width, "height": height,
             "iters_mean": float(it.mean()), "iters_median": float(np.median(it)), "iters_p95": float(np.percentile(it, 95)),
@@ -107,7 +138,7 @@ def sweep_cell(collector: HipCollector, scene, strategy, mode: str, levels, widt
 def run_sweep(scene_names: Optional[Sequence[str]] = None, strategy_names: Optional[Sequence[str]] = None, mode: str = "budget",
               width: int = 384, height: int = 384, budgets: Sequence[int] = DEFAULT_BUDGETS,
               epsilons: Sequence[float] = DEFAULT_EPSILONS, cap: int = 512, hit_threshold: float = 1e-4,
-              out_path: Optional[str] = None, device_id: int = 0, verbose: bool = False) -> List[Dict]:
+              out_path: Optional[str] = None, device_id: int = 0, verbose: bool = False, grid: bool = False) -> List[Dict]:
     """Sweep `mode` over the curated viewpoints of the named scenes (default: all 20) for the named
     strategies (default: all 11).  Unknown names raise KeyError.  Returns the rows; writes CSV (or JSON
     for a .json path) when `out_path` is given."""
@@ -121,7 +152,7 @@ def run_sweep(scene_names: Optional[Sequence[str]] = None, strategy_names: Optio
         for strat in strats:
             if strat.has_lipschitz:
                 strat.lipschitz = scene.known_lipschitz_bound() or 1.0      # run_once wiring (reference main.py:58-61)
-            cell = sweep_cell(collector, scene, strat, mode, levels, width, height)
+            cell = sweep_cell(collector, scene, strat, mode, levels, width, height, grid)
             rows.extend(cell)
             if verbose:
                 print(f"{scene.name:24s} {strat.short_name:24s} {len(cell):3d} frames  "
@@ -160,10 +191,11 @@ def main(argv=None) -> int:
     ap.add_argument("--width", type=int, default=384)
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--out", default="sweep.csv")
+    ap.add_argument("--grid", action="store_true", help="also sweep each strategy's tunable parameters (STRATEGY_PARAM_GRID)")
     a = ap.parse_args(argv)
     rows = run_sweep([s for s in a.scenes.split(",") if s], [s for s in a.strategies.split(",") if s], a.mode, a.width, a.height,
                      [int(v) for v in a.budgets.split(",")], [float(v) for v in a.epsilons.split(",")], a.cap, a.hit_threshold,
-                     a.out, verbose=True)
+                     a.out, verbose=True, grid=a.grid)
     print(f"{len(rows)} rows -> {a.out}")
     return 0
 

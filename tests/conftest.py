@@ -48,6 +48,30 @@ class GoldenFrames:
         }
 
 
+PARAM_ORDER = ["omega", "ar_omega_min", "ar_omega_max", "ar_smoothing", "ar_growth_rate", "ar_decay_rate", "beta",
+               "overstep_min_step", "hybrid_stuck_step_ratio", "hybrid_min_step", "margin", "ar_omega_init",
+               "overstep_bisection_steps", "hybrid_stuck_threshold", "segment_bisection_steps", "revaa_bisection_steps"]
+
+
+def golden_param_cases(tag="48x36"):
+    """frames_params_*.npz: frames the reference's strategy classes marched with NON-default constructor arguments
+    (oracle/gen_golden.py --only params).  Yields (scene id, strategy id, params dict, frame record)."""
+    z = np.load(os.path.join(GOLDEN, f"frames_params_{tag}.npz"))
+    for n in range(int(z["ncases"][0])):
+        p = f"c{n}_"
+        meta = z[p + "meta"]
+        W, H, row0, rows = (int(meta[i]) for i in range(4))
+        hit = np.unpackbits(z[p + "hitbits"])[:rows * W].reshape(rows, W).astype(np.uint8)
+        depth = np.zeros(rows * W, dtype=np.float64)
+        depth[hit.reshape(-1) > 0] = z[p + "t_hit"]
+        prm = {k: (int(v) if k.endswith(("_steps", "_threshold")) else float(v)) for k, v in zip(PARAM_ORDER, z[p + "prm"])}
+        yield int(z[p + "ids"][0]), int(z[p + "ids"][1]), prm, {
+            "W": W, "H": H, "row0": row0, "rows": rows, "max_iterations": int(meta[4]), "hit_threshold": float(meta[5]),
+            "max_distance": float(meta[6]), "lipschitz": float(meta[7]), "cam": z[p + "cam"].copy(),
+            "iters": z[p + "iters"].astype(np.int32), "hit": hit, "depth": depth.reshape(rows, W),
+            "sha_t": z[p + "sha_t"].tobytes(), "sha_fs": z[p + "sha_fs"].tobytes()}
+
+
 def sha_f64(a):
     return hashlib.sha256(np.ascontiguousarray(a, dtype="<f8").tobytes()).digest()
 

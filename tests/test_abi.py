@@ -25,8 +25,9 @@ def test_every_declared_symbol_is_exported():
 
 
 def test_struct_layout_matches_header():
-    src = '#include <stdio.h>\n#include "rm_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu\\n", sizeof(RmMarchConfig),' \
-          'sizeof(RmFrameDesc), sizeof(RmStats), sizeof(RmTiming), sizeof(RmDeviceInfo)); return 0;}\n'
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "rm_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(RmMarchConfig),' \
+          'sizeof(RmFrameDesc), sizeof(RmStats), sizeof(RmTiming), sizeof(RmDeviceInfo), sizeof(RmStrategyParams),' \
+          'offsetof(RmMarchConfig, params), offsetof(RmStrategyParams, overstep_bisection_steps)); return 0;}\n'
     with tempfile.TemporaryDirectory() as td:
         c = os.path.join(td, "s.c")
         open(c, "w").write(src)
@@ -34,7 +35,26 @@ def test_struct_layout_matches_header():
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
         sizes = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
     assert sizes == [ctypes.sizeof(_native.RmMarchConfig), ctypes.sizeof(_native.RmFrameDesc),
-                     ctypes.sizeof(_native.RmStats), ctypes.sizeof(_native.RmTiming), ctypes.sizeof(_native.RmDeviceInfo)]
+                     ctypes.sizeof(_native.RmStats), ctypes.sizeof(_native.RmTiming), ctypes.sizeof(_native.RmDeviceInfo),
+                     ctypes.sizeof(_native.RmStrategyParams), _native.RmMarchConfig.params.offset,
+                     _native.RmStrategyParams.overstep_bisection_steps.offset]
+
+
+def test_default_strategy_params_are_the_reference_defaults():
+    """rm_default_strategy_params (a host-only call) == the defaults of the reference's constructors, and the
+    header documents every field of the binding in the same order."""
+    lib = _native.load()
+    p = _native.RmStrategyParams()
+    lib.rm_default_strategy_params(ctypes.byref(p))
+    assert {n: getattr(p, n) for n, _, _ in _native.STRATEGY_PARAM_FIELDS} == _native.DEFAULT_STRATEGY_PARAMS
+    body = re.search(r"typedef struct RmStrategyParams \{(.*?)\} RmStrategyParams;", _header(), flags=re.S).group(1)
+    fields = re.findall(r"^\s*(?:double|int32_t)\s+(\w+);", body, flags=re.M)
+    assert fields == [n for n, _, _ in _native.STRATEGY_PARAM_FIELDS]
+    c = _native.march_config(params={"omega": 1.6, "overstep_bisection_steps": 8})
+    assert c.use_params == 1 and c.params.omega == 1.6 and c.params.overstep_bisection_steps == 8 and c.params.beta == 0.3
+    assert _native.march_config().use_params == 0
+    with pytest.raises(KeyError):
+        _native.march_config(params={"gain": 2.0})
 
 
 def test_registry_sizes():

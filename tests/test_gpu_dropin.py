@@ -123,7 +123,7 @@ def test_sweep_cells_equal_single_renders(hip, tmp_path):
         cam = Camera(vp.position, vp.target, vp.up, 60.0, w, h).params14()
         lip = (sc.lipschitz or 1.0) if st.key == "Segment" else 1.0
         one = hip.render(hip.make_desc(sc.id, st.id, cam, w, h, max_iterations=r["max_iterations"],
-                                       hit_threshold=r["hit_threshold"], lipschitz=lip), want_evals=True)
+                                       hit_threshold=r["hit_threshold"], lipschitz=lip, full=True), want_evals=True)
         assert r["iters_mean"] == float(one["iters"].mean()) and r["iters_max"] == float(one["iters"].max()), r
         assert r["evals_mean"] == float(one["evals"].mean()) and r["evals_max"] == float(one["evals"].max()), r
         assert r["evals_mean"] >= r["iters_mean"] or r["strategy"] != "Standard"
@@ -197,7 +197,7 @@ def test_gpurunner_render_and_capture(hip):
     # this engine's other strategies by key; GLSL-only ids, non-default shader parameters and bad ids are refused
     px, _ = r.render(10, 0, RenderConfig(width=48, height=36, camera_position=(0.0, 0.0, 3.0)), mc, strategy_key="Curvature")
     assert (np.rint(px[..., 1] * 512).astype(np.int32) == z["s10_k5_iters"]).all()
-    for bad, exc in ((dict(strategy_id=8), ValueError), (dict(strategy_id=0, params={"omega": 1.6}), NotImplementedError),
+    for bad, exc in ((dict(strategy_id=8), ValueError), (dict(strategy_id=3, params={"kappa": 3.0}), NotImplementedError),
                      (dict(strategy_id=0, params={"gain": 1.0}), KeyError)):
         with pytest.raises(exc):
             r.render(0, bad.pop("strategy_id"), rc, mc, **bad)

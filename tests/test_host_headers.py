@@ -7,7 +7,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from conftest import build_native, golden_frames, sha_f64
+from conftest import PARAM_ORDER, build_native, golden_frames, golden_param_cases, sha_f64
 
 
 @pytest.fixture(scope="module")
@@ -15,12 +15,12 @@ def hostlib():
     L = ctypes.CDLL(build_native("host_check"))
     dp = ctypes.POINTER(ctypes.c_double)
     L.rmh_render.argtypes = ([ctypes.c_int] * 3 + [ctypes.c_double] * 3 + [ctypes.c_int, dp] + [ctypes.c_int] * 4
-                             + [ctypes.c_void_p, dp, ctypes.c_void_p, dp])
+                             + [ctypes.c_void_p, dp, ctypes.c_void_p, dp, dp])
     L.rmh_sdf_eval.argtypes = [ctypes.c_int, dp, ctypes.c_size_t, dp]
     return L
 
 
-def _render(L, g, sid, kid, full):
+def _render(L, g, sid, kid, full, prm=None):
     n = g["rows"] * g["W"]
     hit, t = np.empty(n, np.uint8), np.empty(n, np.float64)
     it, fs = np.empty(n, np.int32), np.empty(n, np.float64)
@@ -28,7 +28,8 @@ def _render(L, g, sid, kid, full):
     cam = np.ascontiguousarray(g["cam"])
     rc = L.rmh_render(sid, kid, g["max_iterations"], g["hit_threshold"], g["max_distance"], g["lipschitz"], full,
                       cam.ctypes.data_as(dp), g["W"], g["H"], g["row0"], g["rows"], hit.ctypes.data, t.ctypes.data_as(dp),
-                      it.ctypes.data, fs.ctypes.data_as(dp))
+                      it.ctypes.data, fs.ctypes.data_as(dp),
+                      None if prm is None else np.array([float(prm[k]) for k in PARAM_ORDER]).ctypes.data_as(dp))
     assert rc == 0
     return hit, t, it, fs
 
@@ -68,3 +69,15 @@ def test_tiny_budgets_match_oracle(hostlib):
             assert (it == fr.iters.reshape(-1)).all() and (hit == fr.hit.reshape(-1)).all(), (mi, kid)
             assert (t.view(np.uint64) == fr.t.reshape(-1).view(np.uint64)).all(), (mi, kid)
             assert (fs.view(np.uint64) == fr.final_sdf.reshape(-1).view(np.uint64)).all(), (mi, kid)
+
+
+def test_state_machines_with_non_default_strategy_parameters(hostlib):
+    """StratParams (csrc/rm_core.h) through the resumable state machines, against frames the reference's classes
+    marched with non-default constructor arguments (tests/golden/frames_params_48x36.npz)."""
+    n = 0
+    for sid, kid, prm, g in golden_param_cases():
+        hit, t, it, fs = _render(hostlib, g, sid, kid, 1, prm)
+        assert (it == g["iters"].reshape(-1)).all() and (hit == g["hit"].reshape(-1)).all(), (sid, kid, prm)
+        assert sha_f64(t) == g["sha_t"] and sha_f64(fs) == g["sha_fs"], (sid, kid, prm)
+        n += 1
+    assert n == 140

@@ -119,3 +119,29 @@ def test_csv_schema_is_the_reference_examples():
     for fn, rec in schema.items():
         assert rec["header"] == [""] + cols, fn
         assert rec["index"] == rows, fn
+
+
+def test_strategy_constructor_arguments_follow_the_reference_classes():
+    """get_strategy_by_name(key, **ctor): the reference classes' own keyword names (relaxed_sphere.py:17,
+    auto_relaxed.py:21-23, slope_auto_relaxed.py:25, overstep_bisect.py:18, adaptive_hybrid.py:17-19,
+    segment_tracing.py:26) land in RmStrategyParams fields; short names follow the instance (f-strings of
+    relaxed_sphere.py:26 / slope_auto_relaxed.py:39)."""
+    st = registry.get_strategy_by_name("Relaxed", omega=1.6)
+    assert st.params == {"omega": 1.6} and st.short_name == "Relaxed(ω=1.6)" and st.name == "Relaxed Sphere Tracing (ω=1.6)"
+    assert registry.get_strategy_by_name("Relaxed").short_name == "Relaxed(ω=1.2)" and registry.get_strategy_by_name("Relaxed").params == {}
+    st = registry.get_strategy_by_name("Slope-Auto-Relaxed", beta=0.5)
+    assert st.params == {"beta": 0.5} and st.short_name == "Slope-AR(β=0.5)"
+    st = registry.get_strategy_by_name("Heuristic-Auto-Relaxed", omega_min=1.1, omega_max=2.5, smoothing=0.9, growth_rate=1.02, decay_rate=0.8)
+    assert st.params == {"ar_omega_min": 1.1, "ar_omega_max": 2.5, "ar_smoothing": 0.9, "ar_growth_rate": 1.02, "ar_decay_rate": 0.8}
+    st = registry.get_strategy_by_name("Overstep-Bisect", min_step_factor=0.02, bisection_steps=8)
+    assert st.params == {"overstep_min_step": 0.02, "overstep_bisection_steps": 8}
+    st = registry.get_strategy_by_name("Adaptive-Hybrid", stuck_threshold=3, stuck_step_ratio=0.01, min_step_factor=0.01,
+                                       bisection_steps=12, fallback_to_segment_after=None)      # the last two: never read by march()
+    assert st.params == {"hybrid_stuck_threshold": 3, "hybrid_stuck_step_ratio": 0.01, "hybrid_min_step": 0.01}
+    st = registry.get_strategy_by_name("Segment", lipschitz=2.0, segment_bisection_steps=12)
+    assert st.lipschitz == 2.0 and st.params == {"segment_bisection_steps": 12}
+    assert registry.get_strategy_by_name("Skipping-Spheres", margin=0.1).params == {"margin": 0.1}
+    with pytest.raises(TypeError):
+        registry.get_strategy_by_name("Standard", omega=1.6)
+    with pytest.raises(TypeError):
+        registry.get_strategy_by_name("Relaxed", beta=0.5)

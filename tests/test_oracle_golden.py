@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, golden_frames, sha_f64
+from conftest import GOLDEN, golden_frames, golden_param_cases, sha_f64
 from oracle import oracle
 
 
@@ -27,6 +27,20 @@ def test_oracle_matches_reference(tag):
         assert sha_f64(fr.t) == g["sha_t"], (tag, sid, kid)
         assert sha_f64(fr.final_sdf) == g["sha_fs"], (tag, sid, kid)
         assert (np.where(fr.hit > 0, fr.t, 0.0) == g["depth"]).all()
+
+
+def test_oracle_matches_reference_with_non_default_strategy_parameters():
+    """Strategy constructor arguments (relaxed_sphere.py:17, auto_relaxed.py:21-23, slope_auto_relaxed.py:25,
+    overstep_bisect.py:18, adaptive_hybrid.py:17-19) and the three march() literals (margin, two bisection counts):
+    140 frames the reference marched with non-default values."""
+    n = 0
+    for sid, kid, prm, g in golden_param_cases():
+        fr = oracle.render(sid, kid, g["cam"], g["W"], g["H"], g["row0"], g["rows"], g["max_iterations"],
+                           g["hit_threshold"], g["max_distance"], g["lipschitz"], params=prm)
+        assert (fr.iters == g["iters"]).all() and (fr.hit == g["hit"]).all(), (sid, kid, prm)
+        assert sha_f64(fr.t) == g["sha_t"] and sha_f64(fr.final_sdf) == g["sha_fs"], (sid, kid, prm)
+        n += 1
+    assert n == 140
 
 
 def test_oracle_sdf_points():
