@@ -3,8 +3,9 @@
 
 Metric (BASELINE.json): Mrays/s + mean iterations/ray, 1920x1080 Mandelbulb / Standard, fp64
 parity arithmetic, 1/2/4/8 GPUs.  A "step" is one frame render into HBM-resident depth / iterations /
-hit buffers: the (Mandelbulb, Standard) render kernel plus the two resume passes that finish the rays it
-parked (long-ray suspension, wavefront teams -- DESIGN.md section 3), all on one stream.
+hit buffers: ONE launch of the (Mandelbulb, Standard) pipeline kernel -- producer workgroups render the tiles and
+hand the rays still marching after 48 trips to wavefront teams that run beside them --
+plus the small stats / block-variance kernels, all on one stream.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -207,19 +208,36 @@ def main():
     if L.rm_bench_store_path(W, rows_local, ctypes.c_void_p(p_depth.data_ptr()), ctypes.c_void_p(p_iters.data_ptr()),
                              ctypes.c_void_p(p_hit.data_ptr()), ctypes.byref(tm)) == 0 and tm.ms_median > 0:
         store_gbps = BYTES_PER_RAY * rows_local * W / (tm.ms_median * 1e-3) / 1e9
+    # the same probe at 7680x4320 (BASELINE config 5's frame): a 1080p launch writes 18.7 MB in ~8 us, too short to
+    # fill the memory pipeline; the north star's ">= 40 % of the HBM roofline on the write path" is read at this size
+    store8k_gbps = None
+    if rank == 0:
+        W8, H8 = 7680, 4320
+        q_depth = torch.empty((H8, W8), dtype=torch.float32, device=dev)
+        q_iters = torch.empty((H8, W8), dtype=torch.int32, device=dev)
+        q_hit = torch.empty((H8, W8), dtype=torch.uint8, device=dev)
+        tm8 = _native.RmTiming()
+        tm8.warmup, tm8.repeats = 3, 20
+        if L.rm_bench_store_path(W8, H8, ctypes.c_void_p(q_depth.data_ptr()), ctypes.c_void_p(q_iters.data_ptr()),
+                                 ctypes.c_void_p(q_hit.data_ptr()), ctypes.byref(tm8)) == 0 and tm8.ms_median > 0:
+            store8k_gbps = BYTES_PER_RAY * W8 * H8 / (tm8.ms_median * 1e-3) / 1e9
+        del q_depth, q_iters, q_hit
     # per-pass device time of a frame (events inside the library, between the passes on `stream`): a short
     # untimed loop after the measurement, so the numbers can be held against the rocprofv3 kernel stats
     passes = None
     if L.rm_set_pass_timing(1) == 0:
-        acc_ms, nfr = [0.0] * 3, 5
+        acc_ms, nfr = [0.0] * 4, 5
         for _ in range(nfr):
             step()
             npass = ctypes.c_int32(0)
-            pms = (ctypes.c_float * 3)()
+            pms = (ctypes.c_float * 4)()
             _native.check(L.rm_get_pass_ms(sptr, ctypes.byref(npass), pms))
             for i in range(npass.value):
                 acc_ms[i] += pms[i] / nfr
-        names = ["render_kernel (first pass)", "resume pass 1", "resume pass 2"]
+        # one launch per pass: the kernels one by one; single launch: spans between the marks its waves leave
+        names = (["launch -> tile counter exhausted", "-> last producer wave out of fresh pixels", "-> last producer wave exited",
+                  "-> end of the kernel (teams' tail)"] if npass.value == 4
+                 else ["render_kernel (first pass)", "resume pass 1", "resume pass 2"])
         passes = {names[i]: acc_ms[i] for i in range(npass.value)}
         L.rm_set_pass_timing(0)
     kernel_ms = [a.elapsed_time(b) for a, b in evs]
@@ -240,7 +258,7 @@ def main():
         rays_per_launch = float(st.total_rays)
         achieved = BYTES_PER_RAY * rays_per_launch / (kms * 1e-3) / 1e9
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_r01.json")
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_r02.json")
         if os.path.exists(pmc_path) and args.workload == "mandelbulb-1080p":
             try:
                 traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
@@ -266,10 +284,21 @@ def main():
                          "kernel_ms_avg": kms, "passes_ms": passes, "bytes_per_ray": BYTES_PER_RAY,
                          "store_path_GBps": store_gbps,
                          "store_path_frac": (store_gbps / HBM_PEAK_GBPS) if store_gbps else None,
-                         "note": "write-only path, 9 B/ray; kernel_ms_avg = device time of one frame (all passes, events on "
-                                 "the launch stream), passes_ms = its kernels one by one; the frame is fp64-VALU / "
-                                 "ray-latency bound (DESIGN.md); store_path_* = the flush code alone at this frame size"},
+                         "store_path_8k_GBps": store8k_gbps,
+                         "store_path_8k_frac": (store8k_gbps / HBM_PEAK_GBPS) if store8k_gbps else None,
+                         # what actually binds the frame (the contract's `bound` is hbm | mfma; neither binds this path)
+                         "binding": "fp64 dependent-chain latency of the frame's longest ray (see chain_latency, valu_fp64)",
+                         "note": "write-only path, 9 B/ray; kernel_ms_avg = device time of one frame (events on the launch "
+                                 "stream), passes_ms = its spans / kernels; the frame is fp64-VALU / ray-latency bound "
+                                 "(DESIGN.md); store_path_* = the flush code alone at this frame size, store_path_8k_* = the "
+                                 "same at 7680x4320"},
         }
+        # the longest ray is one dependent chain: iter_max evaluations, each as fast as a wavefront team on an idle
+        # compute unit can run it (13 us measured, tools/prof_straggler.py / DESIGN.md section 3) -- the floor of a frame
+        chain_floor_ms = float(st.iter_max) * 13e-3
+        line["chain_latency"] = {"iter_max": int(st.iter_max), "us_per_evaluation_idle_team": 13.0,
+                                 "floor_ms": chain_floor_ms, "frac": chain_floor_ms / kms if kms > 0 else None,
+                                 "note": "frame time cannot go below the longest ray's chain; frac = floor / measured frame"}
         # what actually bounds the kernel: fp64 vector work.  530 fp64 flop per fractal iteration
         # (SQ_INSTS_VALU_{FMA,ADD,MUL}_F64 of profiles/, one lane) x 1.76 fractal iterations per SDF
         # evaluation on this view -- an estimate, reported next to the vector-fp64 peak.

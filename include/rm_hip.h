@@ -123,6 +123,30 @@ typedef struct RmFrameDesc {
      * one of the three independent transcendental chains of a Mandelbulb trip (rm_march_rays_team), 3 = teams
      * for both resume passes (measured slower than 2; kept for experiments). */
     int32_t resume_mode;
+    /* How the passes of a frame with long-ray suspension are launched.  0 = default (library's choice), 1 = one
+     * launch per pass (first pass, resume, last resume), 2 = ONE launch: producer workgroups render fresh tiles,
+     * take parked rays out of queue 0 as lanes fall idle and park them again at suspend_after[1] trips in queue 1,
+     * which `team_grid` workgroups of wavefront teams consume while the producers are still rendering -- a long ray
+     * moves to the next form the moment it crosses a threshold instead of waiting for a kernel boundary.  Identical
+     * results in every mode.  The remaining fields tune the single launch (0 = library default):
+     *   team_grid        workgroups that run as teams (scenes with a team form; the rest are producers)
+     *   queue_first      1 = idle producer lanes take parked rays before fresh pixels, 2 = fresh pixels first,
+     *                    3 = queue 0 is not used: at suspend_after[0] trips a ray is struck from its tile (the tile is
+     *                    flushed without it) and marches on in its lane until suspend_after[1] (default with teams)
+     *   team_steal       1 = teams take queue 0 entries while queue 1 is empty, 2 = never
+     *   queue_refill_min idle lanes a producer wave needs before it looks at queue 0
+     *   queue_retry      turns between two looks of a producer wave whose lanes stay idle
+     *   team_retry       evaluations between two looks of a team that still carries rays
+     *   age_priority     > 0: a producer wave raises its issue priority to (trips of its oldest ray) / age_priority
+     *                    (capped at 2), so waves carrying old rays win the SIMD they share */
+    int32_t pipeline;
+    int32_t team_grid;
+    int32_t queue_first;
+    int32_t team_steal;
+    int32_t queue_refill_min;
+    int32_t queue_retry;
+    int32_t team_retry;
+    int32_t age_priority;
 } RmFrameDesc;
 
 /* Frame reduce computed in-kernel (the integer part of RayMarchStats.compute, core/types.py:77-137). */
@@ -245,11 +269,14 @@ int rm_render_batch(const RmFrameDesc* shape, int32_t nframes, const double* cam
 int rm_set_queue_capacity(int64_t entries);
 
 /* Per-pass device time of the LAST frame launched (rm_render / rm_render_device / ...): a frame is one
- * render pass plus, with long-ray suspension, up to two resume passes (RmFrameDesc.suspend_after).
+ * render pass plus, with long-ray suspension, up to two resume passes (RmFrameDesc.suspend_after).  For a
+ * single-launch frame (RmFrameDesc.pipeline = 2) four spans inside the one kernel are returned instead, read
+ * from the device clock by the waves themselves: launch -> the tile counter ran out, -> the last producer wave
+ * finished its fresh pixels, -> the last producer wave exited, -> the end of the kernel (the teams' tail).
  * rm_set_pass_timing(1) makes every launch record hipEvents between its passes on the launch stream;
  * rm_get_pass_ms synchronises that stream and returns the count and the milliseconds of each pass
  * (ms must hold RM_MAX_PASSES floats). */
-#define RM_MAX_PASSES 3
+#define RM_MAX_PASSES 4
 int rm_set_pass_timing(int enable);
 int rm_get_pass_ms(void* stream, int32_t* npasses, float* ms);
 

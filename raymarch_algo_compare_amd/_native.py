@@ -97,7 +97,10 @@ class RmFrameDesc(ctypes.Structure):
                 ("band_stride", ctypes.c_int32), ("band_offset", ctypes.c_int32),
                 ("tile_order_mode", ctypes.c_int32), ("eval_mode", ctypes.c_int32),
                 ("suspend_after", ctypes.c_int32 * 2),
-                ("resume_grid", ctypes.c_int32), ("resume_mode", ctypes.c_int32)]
+                ("resume_grid", ctypes.c_int32), ("resume_mode", ctypes.c_int32),
+                ("pipeline", ctypes.c_int32), ("team_grid", ctypes.c_int32), ("queue_first", ctypes.c_int32),
+                ("team_steal", ctypes.c_int32), ("queue_refill_min", ctypes.c_int32), ("queue_retry", ctypes.c_int32),
+                ("team_retry", ctypes.c_int32), ("age_priority", ctypes.c_int32)]
 
 
 class RmOutputs(ctypes.Structure):
@@ -213,7 +216,8 @@ def device_info() -> dict:
 def make_desc(scene_id, strategy_id, cam14, width, height, row0=0, rows=None, max_iterations=512,
               hit_threshold=1e-4, max_distance=100.0, lipschitz=1.0, full=False, tile_rows=0, refill_min=0,
               grid_waves=0, band_rows=0, band_stride=0, band_offset=0, tile_order_mode=0, eval_mode=0,
-              suspend_after=(0, 0), resume_grid=0, resume_mode=0, params: dict | None = None) -> RmFrameDesc:
+              suspend_after=(0, 0), resume_grid=0, resume_mode=0, params: dict | None = None, pipeline=0, team_grid=0,
+              queue_first=0, team_steal=0, queue_refill_min=0, queue_retry=0, team_retry=0, age_priority=0) -> RmFrameDesc:
     d = RmFrameDesc()
     d.scene_id, d.strategy_id = int(scene_id), int(strategy_id)
     d.width, d.height = int(width), int(height)
@@ -237,6 +241,9 @@ def make_desc(scene_id, strategy_id, cam14, width, height, row0=0, rows=None, ma
     d.suspend_after[0], d.suspend_after[1] = int(suspend_after[0]), int(suspend_after[1])
     d.resume_grid = int(resume_grid)
     d.resume_mode = int(resume_mode)
+    d.pipeline, d.team_grid, d.queue_first, d.team_steal = int(pipeline), int(team_grid), int(queue_first), int(team_steal)
+    d.queue_refill_min, d.queue_retry, d.team_retry = int(queue_refill_min), int(queue_retry), int(team_retry)
+    d.age_priority = int(age_priority)
     return d
 
 

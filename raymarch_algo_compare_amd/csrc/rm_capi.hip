@@ -14,6 +14,7 @@
 
 #include "../../include/rm_hip.h"
 #include "rm_kernels.h"
+#include "rm_pipeline.h"
 
 static_assert(RM_HIST_BINS == rm::kHistBins, "histogram size mismatch between ABI and kernels");
 static_assert(RM_NUM_SCENES == 20 && RM_NUM_STRATEGIES == 11, "registry size");
@@ -85,11 +86,21 @@ struct State {
     hipEvent_t ev[2 * RM_MAX_TIMED];
     bool events = false;
     Buf bstats;   // rm_render_batch: the device frame table
+    Buf ctl;      // single-launch pipeline: its hot counters, one per 128-byte line
+    Buf ccost, corder;   // single-launch pipeline: the centre-out tile order of the frame shape `corder_key`
+    long long corder_key[12] = { -1 };
+    bool corder_valid = false;
     // optional per-pass timing of the last frame (rm_set_pass_timing): events around the passes
     bool pass_timing = false;
     hipEvent_t pev[RM_MAX_PASSES + 1];
     bool pev_ready = false;
     int pass_count = 0;
+    bool last_was_pipeline = false;                  // rm_get_pass_ms decodes the in-kernel marks of `last_stats`
+    const unsigned long long* last_stats = nullptr;
+    uint32_t generation = 0;                         // tag of the queue entries of the latest single-launch frame
+    hipEvent_t frame_ev = nullptr;                   // end of the latest frame, on `frame_stream` (frames share one workspace)
+    hipStream_t frame_stream = nullptr;
+    bool frame_ev_valid = false;
 } g;
 
 std::mutex g_mu;
@@ -118,6 +129,10 @@ int check_desc(const RmFrameDesc* d)
     if (d->eval_mode < 0 || d->eval_mode > 2) return fail(RM_E_BAD_ARG, "eval_mode must be 0, 1 or 2");
     if (d->resume_mode < 0 || d->resume_mode > 3) return fail(RM_E_BAD_ARG, "resume_mode must be 0..3");
     if (d->resume_grid < 0) return fail(RM_E_BAD_ARG, "negative resume_grid");
+    if (d->pipeline < 0 || d->pipeline > 2) return fail(RM_E_BAD_ARG, "pipeline must be 0, 1 or 2");
+    if (d->team_grid < 0 || d->queue_first < 0 || d->queue_first > 3 || d->team_steal < 0 || d->team_steal > 2 ||
+        d->queue_refill_min < 0 || d->queue_refill_min > 64 || d->queue_retry < 0 || d->team_retry < 0 || d->age_priority < 0)
+        return fail(RM_E_BAD_ARG, "bad single-launch tuning field");
     if (d->band_rows < 0 || d->band_stride < 0 || d->band_offset < 0) return fail(RM_E_BAD_ARG, "negative band parameter");
     if (d->band_rows > 0 && d->band_stride > 1) {
         const int th = d->tile_rows ? d->tile_rows : 4;
@@ -216,12 +231,13 @@ __global__ __launch_bounds__(1024) void order_tiles_kernel(const int32_t* __rest
 }
 
 // Static centre-out priority: tiles nearer the image centre (where the camera looks) get a higher cost.
-__global__ void center_cost_kernel(int32_t* __restrict__ cost, int tiles_x, int tiles_y, int tile_h, int width, int height,
+__global__ void center_cost_kernel(int32_t* __restrict__ cost, int tiles_x, int tiles_y, int nframes, int tile_h, int width, int height,
                                    int row0, int band_rows, int band_stride, int band_offset)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= tiles_x * tiles_y) return;
-    const int tx = t % tiles_x, ty = t / tiles_x;
+    if (t >= tiles_x * tiles_y * nframes) return;
+    const int tf = t % (tiles_x * tiles_y);               // tile ids run frame-major: every frame of a batch centre-out
+    const int tx = tf % tiles_x, ty = tf / tiles_x;
     const int y0 = ty * tile_h;
     const int gy = band_rows > 0 ? row0 + ((y0 / band_rows) * band_stride + band_offset) * band_rows + (y0 % band_rows) : row0 + y0;
     const float cx = (tx * 64 + 32 - 0.5f * width) / (0.5f * height);      // both axes in units of half the image height
@@ -274,7 +290,19 @@ long long g_queue_cap = kQueueCapMax;           // rm_set_queue_capacity
 
 // Trip budgets of pass 1 / pass 2 (0 = that pass does not park).  desc->suspend_after: 0 = library
 // default, < 0 = off, > 0 = explicit.
-void suspend_levels(const RmFrameDesc* d, int ntiles, int* park)
+// Which launch structure a frame with long-ray suspension uses (RmFrameDesc.pipeline; 0 leaves it to the library).
+// Measured on Mandelbulb, every strategy, 640x360 ... 5120x2880: the single launch is
+// 4-27 % faster than one launch per pass (1080p Standard 11.0-12.4 -> 9.9 ms, Enhanced 9.7 -> 7.9, Hybrid 6.2 ->
+// 5.0, 3840x2160 21.4 -> 15.7 ms); at 7680x4320 the frame is throughput-bound and wants every workgroup as a
+// producer (52.5 ms without suspension, 59 with the pipeline).  Other scenes keep their measured pass schedules.
+int pipeline_mode(const RmFrameDesc* d, int ntiles)
+{
+    if (d->pipeline != 0) return d->pipeline;
+    const long long rays = (long long)ntiles * 256;
+    return (d->scene_id == 10 && rays <= 24000000ll && d->march.max_iterations > 128) ? 2 : 1;
+}
+
+void suspend_levels(const RmFrameDesc* d, int ntiles, int mode, int* park)
 {
     // Default: on for Mandelbulb launches of up to ~16 M rays -- those are bound by the latency of a few
     // hundred 512-trip rays (1080p: 15.2 -> 11.1 ms at 32 / 128 trips; 3840x2160: 22.8 -> 20.2 and
@@ -310,6 +338,14 @@ void suspend_levels(const RmFrameDesc* d, int ntiles, int* park)
     // team form (one sincos per wave) measured slower than single waves -- the evaluation is too short for it.
     if (d->scene_id == 16 && strat_ok && two == 1 && d->suspend_after[0] == 0 && rays <= 16000000ll && d->march.max_iterations > 128)
         park[0] = 24;
+    // Single launch (Mandelbulb): rays are struck from their tile at 16 trips (the tile slot is free again) and handed
+    // to the teams at 48; larger frames, and Segment whose trips evaluate twice, at 32 / 64.  Every strategy gains,
+    // Overstep-Bisect and Skipping-Spheres included (3.56 -> 3.08 ms, 11.3 -> 10.2 ms).
+    if (mode == 2 && d->scene_id == 10 && d->march.max_iterations > 128) {
+        const bool small = rays <= 3000000ll && d->strategy_id != 10;
+        if (d->suspend_after[0] == 0) park[0] = small ? 16 : 32;
+        if (d->suspend_after[1] == 0 && d->suspend_after[0] == 0) park[1] = small ? 48 : 64;
+    }
     if (park[0] == 0) park[1] = 0;
     if (park[1] > 0 && park[1] <= park[0]) park[1] = 0;
 }
@@ -320,8 +356,27 @@ void frame_key(const RmFrameDesc* d, int tile_h, long long* k)
     k[6] = d->band_rows; k[7] = d->band_stride; k[8] = d->band_offset; k[9] = tile_h;
 }
 
+int launch_frame(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, hipStream_t s);
+
 // One frame: (optional) longest-first tile order from the previous frame's costs, stats reset, render.
 int launch(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, hipStream_t s)
+{
+    // The parked-ray queues, tile costs / orders, the control block and the pass events are ONE workspace: frames
+    // are serialised on the device.  A frame enqueued on another stream than the previous one first waits for it
+    // (callers may still overlap their own copies and other kernels with a frame).
+    if (g.frame_ev_valid && g.frame_stream != s) HIP_TRY(hipStreamWaitEvent(s, g.frame_ev, 0));
+    const int rc_frame = launch_frame(d, a, tile_h, grid, s);
+    if (rc_frame) return rc_frame;
+    if (!g.frame_ev_valid) {
+        HIP_TRY(hipEventCreateWithFlags(&g.frame_ev, hipEventDisableTiming));
+        g.frame_ev_valid = true;
+    }
+    HIP_TRY(hipEventRecord(g.frame_ev, s));
+    g.frame_stream = s;
+    return RM_OK;
+}
+
+int launch_frame(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, hipStream_t s)
 {
     HIP_TRY(hipMemsetAsync(a.stats, 0, kStatsBytes, s));
     if (d->rows == 0) return RM_OK;
@@ -345,7 +400,7 @@ int launch(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, hipStre
         if ((rc = g.tcost.ensure((size_t)ntiles * 4)) || (rc = g.torder.ensure((size_t)ntiles * 4))) return rc;
         g.cost_valid = false;                   // tcost is overwritten with the static priorities
         hipLaunchKernelGGL(center_cost_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, s, (int32_t*)g.tcost.p, a.tiles_x,
-                           a.tiles_y, tile_h, a.width, a.height, a.row0, a.band_rows, a.band_stride, a.band_offset);
+                           a.tiles_y, a.nframes, tile_h, a.width, a.height, a.row0, a.band_rows, a.band_stride, a.band_offset);
         hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, s, (const int32_t*)g.tcost.p, (int32_t*)g.torder.p, ntiles);
         HIP_TRY(hipGetLastError());
         a.tile_order = (const int32_t*)g.torder.p;
@@ -353,7 +408,8 @@ int launch(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, hipStre
     // long-ray suspension: pass 1 parks rays beyond suspend_after[0] trips, pass 2 restarts them all at
     // once and parks those beyond suspend_after[1], pass 3 finishes the few that remain
     int park[2];
-    suspend_levels(d, ntiles, park);
+    const int mode = pipeline_mode(d, ntiles);
+    suspend_levels(d, ntiles, mode, park);
     long long* const block_var = a.block_var;
     if (park[0] > 0) {
         const long long total = (long long)a.rows * a.width * a.nframes;
@@ -361,7 +417,12 @@ int launch(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, hipStre
         const int stride = rm::scene(d->scene_id)->entry_bytes(d->strategy_id);
         int rc;
         for (int q = 0; q < (park[1] > 0 ? 2 : 1); ++q) {
-            if ((rc = g.queue[q].ensure((size_t)cap * (size_t)stride))) return rc;
+            const size_t need = (size_t)cap * (size_t)stride;
+            if (need > g.queue[q].cap) {
+                if ((rc = g.queue[q].ensure(need))) return rc;
+                // fresh memory: no word of it may look like a published entry of a later launch (QEntry.ready)
+                HIP_TRY(hipMemsetAsync(g.queue[q].p, 0, need, s));
+            }
             a.queue[q] = (unsigned char*)g.queue[q].p;
         }
         a.queue_cap = (int32_t)cap;
@@ -372,10 +433,77 @@ int launch(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, hipStre
     }
     const bool pt = g.pass_timing && g.pev_ready;
     g.pass_count = 0;
+    g.last_was_pipeline = false;
     if (pt) HIP_TRY(hipEventRecord(g.pev[0], s));
-    HIP_TRY(rm::scene(d->scene_id)->render(d->strategy_id, tile_h, a, grid, s));
+    const rm::SceneLaunchers* const sc = rm::scene(d->scene_id);
+    if (park[0] > 0 && mode == 2) {
+        // ---- the whole frame in ONE launch (rm_pipeline.h): producers + queue-0 consumers + teams side by side
+        const bool teams = sc->has_teams && park[1] > 0 && d->resume_mode != 1;
+        int per_cu = 0;
+        if (sc->occupancy_pipeline(d->strategy_id, a.interleave, a.frames != nullptr, &per_cu) != hipSuccess || per_cu <= 0) per_cu = 2;
+        per_cu = std::min(per_cu, 3);
+        const long long resident = (long long)g.prop.multiProcessorCount * per_cu;
+        const long long max_pwgs = ((long long)ntiles + rm::kPipeWaves - 1) / rm::kPipeWaves;
+        long long team_wgs = 0;
+        if (teams) {
+            // default: a quarter of the resident workgroups (1080p Mandelbulb: 128 of 512; measured)
+            team_wgs = d->team_grid > 0 ? d->team_grid : std::max<long long>(1, resident / 4);
+            team_wgs = std::min<long long>(team_wgs, std::max<long long>(1, resident / 2));
+        }
+        // producers and teams wait for one another (bounded), so the grid never exceeds what is resident at once
+        long long pwgs = d->grid_waves > 0 ? (d->grid_waves + rm::kPipeWaves - 1) / rm::kPipeWaves : resident - team_wgs;
+        pwgs = std::max<long long>(1, std::min<long long>(std::min<long long>(pwgs, max_pwgs), resident - team_wgs));
+        a.team_wgs = (int32_t)team_wgs;
+        a.producer_waves = (int32_t)(pwgs * rm::kPipeWaves);
+        a.suspend_after2 = teams ? park[1] : 0;
+        {
+            int rc2;
+            if ((rc2 = g.ctl.ensure(sizeof(unsigned long long) * rm::kCtlWords))) return rc2;
+            HIP_TRY(hipMemsetAsync(g.ctl.p, 0, sizeof(unsigned long long) * rm::kCtlWords, s));
+            a.ctl = (unsigned long long*)g.ctl.p;
+        }
+        if (++g.generation == 0) g.generation = 1;
+        a.generation = g.generation;
+        // default: with teams, rays below suspend_after[1] never leave their lane (no queue-0 traffic); without
+        // teams queue 0 is the lane-compaction queue, parked rays first
+        a.q0_detach = d->queue_first == 3 || (d->queue_first == 0 && teams);
+        a.q0_first = d->queue_first == 0 ? 1 : (d->queue_first == 1 ? 1 : 0);
+        a.q0_refill_min = d->queue_refill_min > 0 ? d->queue_refill_min : 16;
+        a.q0_retry = d->queue_retry > 0 ? d->queue_retry : 16;
+        a.team_retry = d->team_retry > 0 ? d->team_retry : 4;
+        a.team_steal = d->team_steal == 0 ? 1 : (d->team_steal == 1 ? 1 : 0);
+        a.age_prio = d->age_priority > 0 ? d->age_priority : 0;
+        a.max_spins = 50000;      // ~50 ms of polling: only reached when part of the grid is not resident
+        if (a.tile_cost) HIP_TRY(hipMemsetAsync(a.tile_cost, 0, (size_t)ntiles * 4, s));   // resumed rays may report before the tile flush
+        if (d->tile_order_mode == 0) {
+            // Default tile order of the single launch: centre-out (where the camera looks, the object -- and its
+            // long rays -- start first: 1080p 11.3-12.0 -> 9.9 ms).  A static permutation of the frame shape,
+            // computed once and kept until the shape changes.
+            long long key[12];
+            frame_key(d, tile_h, key);
+            key[10] = a.nframes; key[11] = 2;
+            int rc2;
+            if ((rc2 = g.corder.ensure((size_t)ntiles * 4))) return rc2;
+            if (!g.corder_valid || memcmp(key, g.corder_key, sizeof key) != 0) {
+                if ((rc2 = g.ccost.ensure((size_t)ntiles * 4))) return rc2;
+                hipLaunchKernelGGL(center_cost_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, s, (int32_t*)g.ccost.p, a.tiles_x,
+                                   a.tiles_y, a.nframes, tile_h, a.width, a.height, a.row0, a.band_rows, a.band_stride, a.band_offset);
+                hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, s, (const int32_t*)g.ccost.p, (int32_t*)g.corder.p, ntiles);
+                HIP_TRY(hipGetLastError());
+                memcpy(g.corder_key, key, sizeof key);
+                g.corder_valid = true;
+            }
+            a.tile_order = (const int32_t*)g.corder.p;
+        }
+        HIP_TRY(sc->pipeline(d->strategy_id, a, (int)(pwgs + team_wgs), s));
+        if (pt) HIP_TRY(hipEventRecord(g.pev[++g.pass_count], s));
+        g.last_was_pipeline = true;
+        g.last_stats = a.stats;
+    } else {
+    HIP_TRY(sc->render(d->strategy_id, tile_h, a, grid, s));
     if (pt) HIP_TRY(hipEventRecord(g.pev[++g.pass_count], s));
-    if (park[0] > 0) {
+    }
+    if (park[0] > 0 && mode != 2) {
         rm::KernelArgs b = a;
         b.suspend_after = park[1];
         b.suspend_queue = 1;
@@ -397,17 +525,25 @@ int launch(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, hipStre
                 HIP_TRY(rm::scene(d->scene_id)->resume(d->strategy_id, 1, b, rgrid, s));
             if (pt) HIP_TRY(hipEventRecord(g.pev[++g.pass_count], s));
         }
-        if (block_var) {
-            const long long nb = (long long)(a.width >> 3) * (a.rows >> 2) * a.nframes;
-            if (nb > 0) {
-                hipLaunchKernelGGL(block_var_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, a.iters, a.width,
-                                   a.rows, a.nframes, block_var);
-                HIP_TRY(hipGetLastError());
-            }
+    }
+    if (park[0] > 0 && block_var) {
+        const long long nb = (long long)(a.width >> 3) * (a.rows >> 2) * a.nframes;
+        if (nb > 0) {
+            hipLaunchKernelGGL(block_var_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, a.iters, a.width,
+                               a.rows, a.nframes, block_var);
+            HIP_TRY(hipGetLastError());
         }
     }
     hipLaunchKernelGGL(stats_reduce_kernel, dim3((rm::kStatsWords + 255) / 256), dim3(256), 0, s, a.stats);
     HIP_TRY(hipGetLastError());
+    return RM_OK;
+}
+
+// a single-launch frame whose queue protocol ran into one of its wait bounds (rm_pipeline.h) reports it here
+int check_pipeline_error(const unsigned long long* w)
+{
+    if (w[rm::kWError] != 0)
+        return fail(RM_E_HIP, "single-launch pipeline: a wait of the queue protocol hit its bound (code %llu); results are incomplete", w[rm::kWError]);
     return RM_OK;
 }
 
@@ -536,9 +672,13 @@ void rm_shutdown(void)
     if (!g.ready) return;
     (void)hipSetDevice(g.device);
     (void)hipStreamSynchronize(g.stream);
-    for (Buf* b : { &g.bstats, &g.stats, &g.depth, &g.iters, &g.hit, &g.traw, &g.fs, &g.bvar, &g.evals, &g.in0, &g.in1, &g.out0, &g.out1,
+    g.corder_valid = false;
+    g.cost_valid = false;
+    for (Buf* b : { &g.ccost, &g.corder, &g.ctl, &g.bstats, &g.stats, &g.depth, &g.iters, &g.hit, &g.traw, &g.fs, &g.bvar, &g.evals, &g.in0, &g.in1, &g.out0, &g.out1,
                     &g.out2, &g.out3, &g.tcost, &g.torder, &g.queue[0], &g.queue[1] })
         b->release();
+    if (g.frame_ev_valid) (void)hipEventDestroy(g.frame_ev);
+    g.frame_ev_valid = false;
     if (g.events) for (auto& e : g.ev) (void)hipEventDestroy(e);
     g.events = false;
     if (g.pev_ready) for (auto& e : g.pev) (void)hipEventDestroy(e);
@@ -670,6 +810,7 @@ int rm_render_outputs(const RmFrameDesc* d, const RmOutputs* o, RmStats* stats, 
     unsigned long long w[rm::kStatsWords];
     HIP_TRY(hipMemcpyAsync(w, g.stats.p, kStatsBlockBytes, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
+    if ((rc = check_pipeline_error(w))) return rc;
     if (stats) decode_stats(w, stats);
     return RM_OK;
 }
@@ -708,6 +849,7 @@ int rm_read_stats(const void* d_stats, void* stream, RmStats* out)
     unsigned long long w[rm::kStatsWords];
     HIP_TRY(hipMemcpyAsync(w, d_stats ? d_stats : g.stats.p, kStatsBlockBytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if ((rc = check_pipeline_error(w))) return rc;
     decode_stats(w, out);
     return RM_OK;
 }
@@ -729,6 +871,7 @@ int rm_bench_device(const RmFrameDesc* d, void* d_depth, void* d_iters, void* d_
     if (stats) {
         unsigned long long w[rm::kStatsWords];
         HIP_TRY(hipMemcpy(w, g.stats.p, kStatsBlockBytes, hipMemcpyDeviceToHost));
+        if ((rc = check_pipeline_error(w))) return rc;
         decode_stats(w, stats);
     }
     return RM_OK;
@@ -854,9 +997,26 @@ int rm_get_pass_ms(void* stream, int32_t* npasses, float* ms)
     if (rc) return rc;
     if (!npasses || !ms) return fail(RM_E_BAD_ARG, "NULL output");
     if (!g.pass_timing || !g.pev_ready) return fail(RM_E_BAD_ARG, "pass timing is off (rm_set_pass_timing)");
-    HIP_TRY(hipStreamSynchronize(stream ? (hipStream_t)stream : g.stream));
+    hipStream_t s = stream ? (hipStream_t)stream : g.stream;
+    HIP_TRY(hipStreamSynchronize(s));
     *npasses = g.pass_count;
     for (int i = 0; i < g.pass_count; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], g.pev[i], g.pev[i + 1]));
+    if (g.last_was_pipeline && g.pass_count == 1 && g.last_stats) {
+        // one kernel: split its time at the marks its waves left in the stats block (100 MHz device clock)
+        unsigned long long w[rm::kStatsHead];
+        HIP_TRY(hipMemcpyAsync(w, g.last_stats, sizeof w, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        const unsigned long long start = ~w[rm::kWMarkStart], tiles = ~w[rm::kWMarkTiles];
+        if (w[rm::kWMarkStart] != 0 && w[rm::kWMarkTiles] != 0 && tiles >= start && w[rm::kWMarkFresh] >= tiles &&
+            w[rm::kWMarkProd] >= w[rm::kWMarkFresh]) {
+            const float total = ms[0];
+            const float t_tiles = (float)((double)(tiles - start) * 1e-5);
+            const float fresh = (float)((double)(w[rm::kWMarkFresh] - start) * 1e-5);
+            const float prod = (float)((double)(w[rm::kWMarkProd] - start) * 1e-5);
+            ms[0] = t_tiles; ms[1] = fresh - t_tiles; ms[2] = prod - fresh; ms[3] = std::max(0.f, total - prod);
+            *npasses = 4;
+        }
+    }
     return RM_OK;
 }
 
@@ -874,6 +1034,7 @@ int rm_alloc_frame(int32_t width, int32_t rows, void** d_depth, void** d_iters, 
     int rc = check_ready();
     if (rc) return rc;
     if (width <= 0 || rows <= 0 || !d_depth || !d_iters || !d_hit) return fail(RM_E_BAD_ARG, "bad arguments");
+    std::lock_guard<std::mutex> lk(g_mu);
     HIP_TRY(hipSetDevice(g.device));
     const size_t n = (size_t)width * rows;
     HIP_TRY(hipMalloc(d_depth, n * 4));
@@ -886,6 +1047,7 @@ int rm_free_frame(void* d_depth, void* d_iters, void* d_hit)
 {
     int rc = check_ready();
     if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
     HIP_TRY(hipSetDevice(g.device));
     if (d_depth) HIP_TRY(hipFree(d_depth));
     if (d_iters) HIP_TRY(hipFree(d_iters));
@@ -898,6 +1060,7 @@ int rm_copy_frame_to_host(int32_t width, int32_t rows, const void* d_depth, cons
 {
     int rc = check_ready();
     if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
     HIP_TRY(hipSetDevice(g.device));
     const size_t n = (size_t)width * rows;
     HIP_TRY(hipStreamSynchronize(g.stream));

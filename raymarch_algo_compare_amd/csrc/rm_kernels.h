@@ -47,7 +47,7 @@ namespace rm {
 
 constexpr int kTileW = 64;          // one tile row == one wavefront-wide store
 constexpr int kHistBins = 544;      // iterations <= max_iterations + 9 (Segment 521, RevAA 520) for 512
-constexpr int kStatsHead = 16;
+constexpr int kStatsHead = 24;
 constexpr int kStatsWords = kStatsHead + kHistBins;  // u64 words, layout below
 constexpr int kQueues = 2;          // suspended-ray queues (ping-pong between resume levels)
 // The frame totals and the histogram are accumulated in kStatsParts partial blocks (workgroup % kStatsParts)
@@ -60,7 +60,8 @@ constexpr int kStatsBlocks = 1 + kStatsParts;
 // device-side stats block (u64 words):
 //  [0] tile counter   [1] hit_count   [2] sum_iters   [3] iter_max   [4] 0x7fffffff - iter_min
 //  [5] rays written   [6..7] entries pushed to suspended-ray queue 0 / 1   [8..9] entries handed out
-//  of queue 0 / 1   [10] SDF evaluations of the finished rays   [11..15] reserved
+//  of queue 0 / 1   [10] SDF evaluations of the finished rays   [11..15] single-launch pipeline: progress counters
+//  and time marks (rm_pipeline.h)   [16] pipeline protocol error (0 = none)   [17..23] reserved
 //  [16 .. 16+kHistBins) histogram of iterations
 // Block 0 holds the counters ([0], [6..9]) and, after stats_reduce_kernel, the totals; blocks 1..kStatsParts
 // hold the partial sums of words [1..5], [10] and of the histogram.
@@ -100,6 +101,21 @@ struct KernelArgs {
     unsigned char* queue[kQueues];
     const int32_t* tile_order;  // optional: permutation of the tile ids (longest-first schedule)
     int32_t* tile_cost;         // optional: per tile, the largest iteration count of its rays
+    // Single-launch pipeline (rm_pipeline.h): workgroups [0, team_wgs) are wavefront teams, the rest producers
+    // (`producer_waves` waves in all); rays resumed from queue 0 are parked again at suspend_after2 trips in
+    // queue 1, which the teams consume.  `generation` tags the queue entries of this launch.
+    unsigned long long* ctl;    // the launch's hot counters, one per 128-byte line (rm_pipeline.h), zeroed before the launch
+    int32_t team_wgs, producer_waves;
+    uint32_t generation;
+    int32_t suspend_after2;
+    int32_t q0_first;           // idle lanes take parked rays before fresh pixels (else only once the wave has no fresh pixels left)
+    int32_t q0_detach;          // queue 0 unused: a ray at suspend_after trips is struck from its tile and marches on in its lane
+    int32_t q0_refill_min;      // idle lanes required before a wave looks at queue 0
+    int32_t q0_retry;           // turns between two looks at queue 0 while lanes idle
+    int32_t team_retry;         // evaluations between two looks of a team with idle lanes
+    int32_t team_steal;         // teams take queue 0 entries while queue 1 is empty
+    int32_t max_spins;          // polls after which a producer wave with nothing to do stops waiting for the others
+    int32_t age_prio;           // > 0: a producer wave's issue priority = (trips of its oldest ray) / age_prio, capped at 2
 };
 
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -165,6 +181,8 @@ template <class Strat>
 struct QEntry {
     uint32_t gi;
     uint32_t nev;   // SDF evaluations performed so far (KernelArgs.evals)
+    uint32_t ready; // single-launch pipeline: == KernelArgs.generation once the entry is published (rm_pipeline.h)
+    uint32_t pad;
     Strat s;
 };
 
@@ -175,11 +193,14 @@ __device__ __forceinline__ bool push_suspended(const KernelArgs& a, int q, bool 
 {
     const unsigned long long m = __ballot(want);
     if (m == 0) return false;
-    unsigned int base = 0;
-    if (lane_id() == 0) base = (unsigned int)atomicAdd(&a.stats[6 + q], (unsigned long long)__popcll(m));
-    base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
-    const unsigned int idx = base + (unsigned int)rank_in_mask(m);
-    const bool ok = want && idx < (unsigned int)a.queue_cap;
+    // 64-bit throughout: rays refused by a full queue bump the counter again on later turns, and a counter
+    // truncated to 32 bits could wrap back below queue_cap and overwrite live entries
+    unsigned long long base = 0;
+    if (lane_id() == 0) base = atomicAdd(&a.stats[6 + q], (unsigned long long)__popcll(m));
+    base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    const unsigned long long idx = base + (unsigned long long)rank_in_mask(m);
+    const bool ok = want && idx < (unsigned long long)a.queue_cap;
     if (ok) {
         QEntry<Strat>* e = (QEntry<Strat>*)a.queue[q] + idx;
         e->gi = gi;
@@ -866,12 +887,15 @@ __global__ __launch_bounds__(64 * kTeam) void resume_team_kernel(const KernelArg
         if (a.suspend_after > 0 && __any(park)) {
             // park the longest rays once more: wave 0 reserves the queue slots, every wave learns the outcome
             const unsigned long long m = __ballot(park);
-            if (part == 0 && lane == 0) s_base = (unsigned int)atomicAdd(&a.stats[6 + a.suspend_queue], (unsigned long long)__popcll(m));
+            if (part == 0 && lane == 0) {
+                const unsigned long long b64 = atomicAdd(&a.stats[6 + a.suspend_queue], (unsigned long long)__popcll(m));
+                s_base = b64 > 0xffffff00ull ? 0xffffff00u : (unsigned int)b64;      // saturate: never wraps below queue_cap
+            }
             __syncthreads();
             const unsigned int base = (unsigned int)__builtin_amdgcn_readfirstlane((int)s_base);
             __syncthreads();
-            const unsigned int idx = base + (unsigned int)rank_in_mask(m);
-            if (park && idx < (unsigned int)a.queue_cap) {
+            const unsigned long long idx = (unsigned long long)base + (unsigned long long)rank_in_mask(m);
+            if (park && idx < (unsigned long long)a.queue_cap) {
                 if (part == 0) {
                     Entry* e = (Entry*)a.queue[a.suspend_queue] + idx;
                     e->gi = my_gi;
@@ -897,6 +921,9 @@ struct SceneLaunchers {
     hipError_t (*render)(int strategy, int tile_h, const KernelArgs& a, int grid, hipStream_t s);
     hipError_t (*resume)(int strategy, int level, const KernelArgs& a, int grid, hipStream_t s);
     hipError_t (*resume_team)(int strategy, int level, const KernelArgs& a, int grid, hipStream_t s);   // nullptr: no team form
+    hipError_t (*pipeline)(int strategy, const KernelArgs& a, int grid, hipStream_t s);                  // rm_pipeline.h
+    hipError_t (*occupancy_pipeline)(int strategy, int interleave, int batch, int* blocks_per_cu);
+    bool has_teams;
     int (*entry_bytes)(int strategy);   // sizeof(QEntry<Strat>)
     hipError_t (*occupancy)(int strategy, int tile_h, int interleave, int batch, int* blocks_per_cu);
     hipError_t (*sdf_eval)(const double* xyz, size_t n, double* out, hipStream_t s);

@@ -2,6 +2,7 @@
 // Instantiates render / march_rays kernels for every strategy and the sdf_eval kernel
 // of that scene, and exports their launchers through rm::scene_launchers_<id>().
 #include "rm_kernels.h"
+#include "rm_pipeline.h"
 
 #ifndef RM_SCENE_ID
 #error "compile with -DRM_SCENE_ID=<scene id>"
@@ -55,6 +56,55 @@ static hipError_t occ_render(int interleave, int batch, int* blocks)
     }
     if (il) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, render_kernel<SceneT, Strat, TH, kIter, false>, 64 * kWavesPerWG, 0);
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, render_kernel<SceneT, Strat, TH, false, false>, 64 * kWavesPerWG, 0);
+}
+
+template <class Strat>
+static hipError_t launch_pipeline(const KernelArgs& a, int grid, hipStream_t s)
+{
+    const bool il = kIter && a.interleave;
+    const dim3 g(grid), b(64 * kPipeWaves);
+    if (a.frames) {
+        if (il) hipLaunchKernelGGL((pipeline_kernel<SceneT, Strat, 4, kIter, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((pipeline_kernel<SceneT, Strat, 4, false, true>), g, b, 0, s, a);
+    } else {
+        if (il) hipLaunchKernelGGL((pipeline_kernel<SceneT, Strat, 4, kIter, false>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((pipeline_kernel<SceneT, Strat, 4, false, false>), g, b, 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+template <class Strat>
+static hipError_t occ_pipeline(int interleave, int batch, int* blocks)
+{
+    const bool il = kIter && interleave;
+    if (batch) {
+        if (il) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pipeline_kernel<SceneT, Strat, 4, kIter, true>, 64 * kPipeWaves, 0);
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pipeline_kernel<SceneT, Strat, 4, false, true>, 64 * kPipeWaves, 0);
+    }
+    if (il) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pipeline_kernel<SceneT, Strat, 4, kIter, false>, 64 * kPipeWaves, 0);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pipeline_kernel<SceneT, Strat, 4, false, false>, 64 * kPipeWaves, 0);
+}
+
+static hipError_t pipeline(int strategy, const KernelArgs& a, int grid, hipStream_t s)
+{
+    switch (strategy) {
+#define RM_X(id, S) \
+    case id: return launch_pipeline<S>(a, grid, s);
+        RM_STRATEGY_LIST(RM_X)
+#undef RM_X
+    }
+    return hipErrorInvalidValue;
+}
+
+static hipError_t occupancy_pipeline(int strategy, int interleave, int batch, int* blocks)
+{
+    switch (strategy) {
+#define RM_X(id, S) \
+    case id: return occ_pipeline<S>(interleave, batch, blocks);
+        RM_STRATEGY_LIST(RM_X)
+#undef RM_X
+    }
+    return hipErrorInvalidValue;
 }
 
 static hipError_t render(int strategy, int tile_h, const KernelArgs& a, int grid, hipStream_t s)
@@ -165,8 +215,8 @@ static hipError_t march_rays_team_impl(int strategy, const MarchCfg& cfg, const 
 // a host function (not a const global: hipcc would try to emit that for the device too)
 const SceneLaunchers* RM_CAT(scene_launchers_, RM_SCENE_ID)()
 {
-    static const SceneLaunchers l = { render, resume, kIter ? resume_team_impl<kIter> : nullptr, entry_bytes, occupancy, sdf_eval, march_rays,
-                                      kIter ? march_rays_team_impl<kIter> : nullptr };
+    static const SceneLaunchers l = { render, resume, kIter ? resume_team_impl<kIter> : nullptr, pipeline, occupancy_pipeline, kIter,
+                                      entry_bytes, occupancy, sdf_eval, march_rays, kIter ? march_rays_team_impl<kIter> : nullptr };
     return &l;
 }
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity campaign on a GPU box: random (scene, strategy), frame size, camera, march configuration and
 SCHEDULE knobs (evaluation mode, suspension budgets, resume mode, refill threshold, grid size, tile order, row
-shards) against the CPU oracle, bit for bit (iterations, hits, raw fp64 t, final_sdf, frame totals).
+shards, one launch per pass or the single-launch pipeline with its team / queue knobs) against the CPU oracle, bit for bit (iterations, hits, raw fp64 t, final_sdf, frame totals).
 usage: python tests/fuzz_parity.py [cases] [seed]      (test infrastructure, lives under tests/: it loads oracle/)"""
 import json
 import os
@@ -35,7 +35,12 @@ def one_case(rng):
     b1 = 0 if b0 <= 0 else int(rng.choice([0, 0, b0 + 1, b0 * 3, 100]))
     sched = dict(eval_mode=int(rng.integers(0, 3)), suspend_after=(b0, b1), resume_mode=int(rng.integers(0, 4)),
                  refill_min=int(rng.choice([0, 1, 8, 33, 64])), grid_waves=int(rng.choice([0, 0, 4, 64, 1000])),
-                 tile_order_mode=int(rng.choice([0, 0, 1, 2])), resume_grid=int(rng.choice([0, 0, 1, 7, 300])))
+                 tile_order_mode=int(rng.choice([0, 0, 1, 2])), resume_grid=int(rng.choice([0, 0, 1, 7, 300])),
+                 # launch structure: passes / single launch, and the single launch's knobs
+                 pipeline=int(rng.choice([0, 1, 2, 2])), team_grid=int(rng.choice([0, 0, 1, 3, 40, 700])),
+                 queue_first=int(rng.integers(0, 4)), team_steal=int(rng.integers(0, 3)),
+                 queue_refill_min=int(rng.choice([0, 1, 16, 64])), queue_retry=int(rng.choice([0, 1, 5, 100])),
+                 team_retry=int(rng.choice([0, 1, 3, 50])), age_priority=int(rng.choice([0, 0, 1, 16, 40])))
     desc = _native.make_desc(sid, kid, cam, w, h, row0, rows, mi, thr, far, lip, True, **sched)
     out = _native.render(desc, want_t_raw=True, want_final_sdf=True)
     ref = oracle.render(sid, kid, cam, w, h, row0=row0, rows=rows, max_iterations=mi, hit_threshold=thr, max_distance=far, lipschitz=lip)

@@ -60,7 +60,7 @@ def test_default_strategy_params_are_the_reference_defaults():
 def test_registry_sizes():
     lib = _native.load()
     assert lib.rm_num_scenes() == 20 and lib.rm_num_strategies() == 11
-    assert lib.rm_stats_device_bytes() == 8 * (16 + _native.RM_HIST_BINS) * 65   # canonical block + 64 partial blocks
+    assert lib.rm_stats_device_bytes() == 8 * (24 + _native.RM_HIST_BINS) * 65   # canonical block + 64 partial blocks
 
 
 def test_no_cpu_fallback_without_device():

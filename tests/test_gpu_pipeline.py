@@ -1,0 +1,136 @@
+"""The single-launch pipeline (RmFrameDesc.pipeline = 2, csrc/rm_pipeline.h): producers, queue-0 consumers and
+wavefront teams side by side in one kernel.  Who marches a ray, and when, depends on timing -- the results must
+not: every knob combination is checked against the reference-generated goldens / the pinned oracle, bit for bit."""
+import numpy as np
+import pytest
+
+from conftest import golden_frames, golden_param_cases, sha_f64
+from test_gpu_parity import _check, _render
+
+pytestmark = pytest.mark.gpu
+
+KNOBS = [dict(), dict(team_grid=1), dict(team_grid=5, queue_first=2), dict(team_grid=300, team_steal=2), dict(queue_first=3, team_grid=7),
+         dict(queue_first=1),
+         dict(queue_first=1, queue_refill_min=1, queue_retry=1, team_retry=1), dict(queue_refill_min=64, queue_retry=50, team_retry=20),
+         dict(grid_waves=4, team_grid=2), dict(grid_waves=1000, team_grid=64, refill_min=1), dict(resume_mode=1)]
+
+
+def test_mandelbulb_every_strategy_single_launch(hip):
+    """Mandelbulb x 11 strategies at 64x48 under tiny budgets (nearly every ray crosses both queues), both
+    evaluation modes, every knob set."""
+    G = golden_frames("64x48")
+    for kid in range(11):
+        g = G.get(10, kid)
+        for budgets in ((6, 40), (1, 2), (8, 0), (3, 200)):
+            for i, knobs in enumerate(KNOBS):
+                out = _render(hip, g, 10, kid, True, pipeline=2, suspend_after=budgets, eval_mode=1 + (i + kid) % 2, **knobs)
+                assert _check(out, g, 10) == (0, 0), (kid, budgets, knobs)
+
+
+def test_other_scenes_single_launch(hip):
+    """The pipeline is generic: scenes without a team form run producers + queue 0 only; the union scenes have teams."""
+    G = golden_frames("160x120")
+    cells = [p for p in G.pairs if p[0] in (0, 2, 9, 12)]
+    for sid, kid in cells:
+        g = G.get(sid, kid)
+        for sched in (dict(suspend_after=(4, 0)), dict(suspend_after=(5, 23), team_grid=3), dict(suspend_after=(2, 0), queue_first=2)):
+            out = _render(hip, g, sid, kid, True, pipeline=2, **sched)
+            assert _check(out, g, sid) == (0, 0), (sid, kid, sched)
+    G = golden_frames("64x48")
+    for sid in (1, 13, 14, 15, 16):
+        for kid in (0, 5, 8, 10):
+            g = G.get(sid, kid)
+            for sched in (dict(suspend_after=(4, 19)), dict(suspend_after=(3, 0), team_grid=2), dict(suspend_after=(16, 64), team_steal=2)):
+                out = _render(hip, g, sid, kid, True, pipeline=2, **sched)
+                assert _check(out, g, sid) == (0, 0), (sid, kid, sched)
+
+
+def test_full_frames_1080p_single_launch_equal_the_oracle(hip):
+    """The bench configuration itself: Mandelbulb 1920x1080, three strategies, single launch at the default budgets
+    and at two other settings -- every ray against the oracle."""
+    import os
+    from oracle import oracle
+    from raymarch_algo_compare_amd import registry
+    from raymarch_algo_compare_amd.camera import Camera
+    W, H = 1920, 1080
+    sc = registry.SCENES[10]
+    cam = Camera(sc.camera_position, sc.camera_target, (0.0, 1.0, 0.0), 60.0, W, H).params14()
+    nt = max(1, (os.cpu_count() or 2) - 1)
+    for kid, scheds in ((0, (dict(), dict(suspend_after=(32, 64), team_grid=96, tile_order_mode=2), dict(suspend_after=(16, 48), queue_first=2, team_steal=2))),
+                        (4, (dict(),)), (10, (dict(team_grid=200),))):
+        ref = oracle.render(10, kid, cam, W, H, nthreads=nt)
+        for sched in scheds:
+            out = hip.render(hip.make_desc(10, kid, cam, W, H, full=True, pipeline=2, **sched), want_t_raw=True, want_final_sdf=True,
+                             want_block_var=True)
+            assert (out["iters"] == ref.iters).all() and (out["hit"] == ref.hit).all(), (kid, sched)
+            assert (out["t_raw"].view(np.uint64) == ref.t.view(np.uint64)).all(), (kid, sched)
+            assert (out["final_sdf"].view(np.uint64) == ref.final_sdf.view(np.uint64)).all(), (kid, sched)
+            st = out["stats"]
+            assert st["total_rays"] == W * H and st["sum_iters"] == int(ref.iters.sum(dtype=np.int64)) and st["hit_count"] == int(ref.hit.sum())
+            assert (st["iter_hist"] == np.bincount(ref.iters.ravel(), minlength=len(st["iter_hist"]))).all()
+            from raymarch_algo_compare_amd.stats import warp_divergence_from_block_var, warp_divergence_proxy
+            assert warp_divergence_from_block_var(out["block_var"]) == warp_divergence_proxy(ref.iters)
+
+
+def test_batches_shards_parameters_and_full_queues_single_launch(hip):
+    """Everything that rides on a parked ray in the single launch: its frame (batches), its row shard, its strategy
+    parameters, its evaluation count; and queues too small for the rays that want to park."""
+    import math
+    from oracle import oracle
+    from raymarch_algo_compare_amd import registry
+    from raymarch_algo_compare_amd.camera import Camera
+    # batches with per-frame parameters
+    groups = {}
+    for sid, kid, prm, g in golden_param_cases():
+        if sid == 10 and kid in (1, 6, 9):
+            groups.setdefault(kid, []).append((prm, g))
+    for kid, cases in groups.items():
+        g0 = cases[0][1]
+        cfgs = [dict(max_iterations=512, lipschitz=g["lipschitz"], params=prm) for prm, g in cases]
+        shape = hip.make_desc(10, kid, g0["cam"], g0["W"], g0["H"], pipeline=2, suspend_after=(3, 11), team_grid=2)
+        out = hip.render_batch(shape, np.stack([g["cam"] for _, g in cases]), cfgs)
+        for i, (prm, g) in enumerate(cases):
+            assert (out["iters"][i] == g["iters"]).all() and (out["hit"][i] == g["hit"]).all(), (kid, i)
+    # ragged frames, row shards, band-cyclic shards
+    sc = registry.SCENES[10]
+    for w, h in ((100, 37), (67, 50)):
+        cam = Camera(sc.camera_position, sc.camera_target, (0.0, 1.0, 0.0), 60.0, w, h).params14()
+        ref = oracle.render(10, 0, cam, w, h)
+        for kw in (dict(), dict(row0=8, rows=16), dict(row0=0, rows=12, band_rows=4, band_stride=3, band_offset=1)):
+            out = hip.render(hip.make_desc(10, 0, cam, w, h, full=True, pipeline=2, suspend_after=(5, 30), **kw), want_t_raw=True,
+                             want_evals=True)
+            rows = ([kw["row0"] + ((y // 4) * 3 + 1) * 4 + y % 4 for y in range(kw["rows"])] if "band_rows" in kw
+                    else list(range(kw.get("row0", 0), kw.get("row0", 0) + kw.get("rows", h))))
+            assert (out["iters"] == ref.iters[rows]).all() and (out["t_raw"].view(np.uint64) == ref.t[rows].view(np.uint64)).all(), (w, h, kw)
+            one = hip.render(hip.make_desc(10, 0, cam, w, h, full=True, suspend_after=(-1, -1), **kw), want_evals=True)
+            assert (out["evals"] == one["evals"]).all()
+    # queues of 100 entries
+    G = golden_frames("160x120")
+    L = hip.load()
+    try:
+        hip.check(L.rm_set_queue_capacity(100))
+        for kid in (0, 6):
+            g = G.get(10, kid)
+            for sched in (dict(suspend_after=(2, 9)), dict(suspend_after=(3, 0)), dict(suspend_after=(2, 9), team_grid=1, team_steal=2)):
+                assert _check(_render(hip, g, 10, kid, True, pipeline=2, **sched), g, 10) == (0, 0), (kid, sched)
+    finally:
+        hip.check(L.rm_set_queue_capacity(0))
+    # temporal tile order across single-launch frames (costs of resumed rays arrive before or after the tile flush)
+    g = G.get(10, 0)
+    for _ in range(3):
+        assert _check(_render(hip, g, 10, 0, False, pipeline=2, suspend_after=(8, 40), tile_order_mode=1), g, 10) == (0, 0)
+
+
+def test_pass_marks_of_a_single_launch(hip):
+    """rm_get_pass_ms splits a single-launch frame at the marks its waves leave: four non-negative spans."""
+    import ctypes
+    g = golden_frames("160x120").get(10, 0)
+    L = hip.load()
+    hip.check(L.rm_set_pass_timing(1))
+    try:
+        _render(hip, g, 10, 0, False, pipeline=2, suspend_after=(8, 40))
+        n, ms = ctypes.c_int32(0), (ctypes.c_float * 4)()
+        hip.check(L.rm_get_pass_ms(None, ctypes.byref(n), ms))
+        assert n.value == 4 and all(ms[i] >= 0.0 for i in range(4)) and sum(ms) > 0.0
+    finally:
+        hip.check(L.rm_set_pass_timing(0))

@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Developer experiments for the single-launch pipeline (RmFrameDesc.pipeline = 2) on a GPU box -- not product,
+not tests.  Usage: python tools/dev_pipe.py <exp>    exp = first | teams | budgets | sizes | strategies"""
+import ctypes, sys, os, json, itertools
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from raymarch_algo_compare_amd import _native, registry
+from raymarch_algo_compare_amd.camera import Camera
+
+
+def cam_for(scene, W, H):
+    return Camera(scene.camera_position or (0.0, 0.0, 5.0), scene.camera_target or (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 60.0, W, H)
+
+
+def run(sid=10, kid=0, W=1920, H=1080, repeats=7, warmup=2, **tuning):
+    scene = registry.SCENES[sid]
+    L = _native.init()
+    desc = _native.make_desc(sid, kid, cam_for(scene, W, H).params14(), W, H, **tuning)
+    _native.check(L.rm_set_pass_timing(1))
+    out = _native.render(desc, warmup=warmup, repeats=repeats)
+    n, ms = ctypes.c_int32(0), (ctypes.c_float * 4)()
+    _native.check(L.rm_get_pass_ms(None, ctypes.byref(n), ms))
+    _native.check(L.rm_set_pass_timing(0))
+    st = out["stats"]
+    r = dict(ms=round(out["timing"]["ms_median"], 3), ms_min=round(out["timing"]["ms_min"], 3),
+             mrays=round(W * H / out["timing"]["ms_median"] / 1e3, 1), passes=[round(ms[i], 3) for i in range(n.value)],
+             sum_iters=st["sum_iters"], **{k: v for k, v in tuning.items()})
+    if (W, H) != (1920, 1080): r["WxH"] = f"{W}x{H}"
+    if (sid, kid) != (10, 0): r["cell"] = f"{scene.name}/{registry.list_strategies()[kid]}"
+    print(json.dumps(r), flush=True)
+    return r
+
+
+exp = sys.argv[1] if len(sys.argv) > 1 else "first"
+if exp == "tune":
+    run(pipeline=1, tile_order_mode=2)
+    base = dict(pipeline=2, tile_order_mode=2, team_grid=128)
+    for b in ((16, 48), (32, 48), (24, 56), (32, 64)):
+        run(suspend_after=b, **base)
+        for ap in (16, 24, 32):
+            run(suspend_after=b, age_priority=ap, **base)
+    for tg in (96, 112, 144, 160):
+        run(suspend_after=(16, 48), **dict(base, team_grid=tg))
+    for kw in (dict(team_retry=1), dict(team_retry=2), dict(team_retry=8), dict(refill_min=4), dict(refill_min=16), dict(refill_min=24)):
+        run(suspend_after=(16, 48), **base, **kw)
+    run(suspend_after=(16, 48), **dict(base, tile_order_mode=1))
+    run(suspend_after=(16, 48), **dict(base, tile_order_mode=0))
+elif exp == "cu":
+    run(pipeline=1, tile_order_mode=2)
+    for tg in (16, 32, 48, 64, 96):
+        for b in ((32, 64), (32, 48), (16, 32), (24, 40), (32, 128)):
+            run(pipeline=2, tile_order_mode=2, suspend_after=b, team_grid=tg)
+    for b in ((32, 64), (32, 48)):
+        run(pipeline=2, tile_order_mode=1, suspend_after=b, team_grid=48)
+        run(pipeline=2, tile_order_mode=0, suspend_after=b, team_grid=48)
+elif exp == "poll":
+    run(pipeline=1, tile_order_mode=2)
+    for tg in (32, 64, 128, 256):
+        for b in ((32, 64), (32, 48), (16, 48), (32, 128)):
+            run(pipeline=2, tile_order_mode=2, suspend_after=b, team_grid=tg)
+    for b in ((32, 64), (32, 48)):
+        run(pipeline=2, tile_order_mode=1, suspend_after=b, team_grid=128)
+        run(pipeline=2, tile_order_mode=0, suspend_after=b, team_grid=128)
+elif exp == "detach":
+    run(pipeline=1)
+    run(pipeline=1, tile_order_mode=2)
+    for b in ((32, 64), (32, 128), (16, 64), (32, 48), (32, 96), (24, 48)):
+        for tg in (64, 128, 192):
+            run(pipeline=2, tile_order_mode=2, suspend_after=b, team_grid=tg)
+    run(pipeline=2, suspend_after=(32, 64), team_grid=128)
+    run(pipeline=2, tile_order_mode=1, suspend_after=(32, 64), team_grid=128)
+    for tr in (1, 2, 8):
+        run(pipeline=2, tile_order_mode=2, suspend_after=(32, 64), team_grid=128, team_retry=tr)
+elif exp == "first":
+    run(pipeline=1)
+    run(pipeline=1, tile_order_mode=2)
+    run(pipeline=2)
+    run(pipeline=2, tile_order_mode=2)
+    for tg in (32, 64, 96, 128, 192, 256):
+        run(pipeline=2, tile_order_mode=2, team_grid=tg)
+    for b in ((32, 64), (32, 96), (32, 128), (16, 64), (24, 64), (48, 96), (32, 48)):
+        run(pipeline=2, tile_order_mode=2, suspend_after=b)
+        run(pipeline=2, tile_order_mode=2, suspend_after=b, team_grid=64)
+    for qf, ts in itertools.product((1, 2), (1, 2)):
+        run(pipeline=2, tile_order_mode=2, queue_first=qf, team_steal=ts)
+        run(pipeline=2, tile_order_mode=2, queue_first=qf, team_steal=ts, suspend_after=(32, 64))
+elif exp == "teams":
+    for tg in (16, 32, 48, 64, 96, 128, 160, 192, 256, 320):
+        for b in ((32, 64), (32, 128)):
+            run(pipeline=2, tile_order_mode=2, team_grid=tg, suspend_after=b)
+elif exp == "knobs":
+    for kw in (dict(queue_refill_min=8), dict(queue_refill_min=32), dict(queue_retry=4), dict(queue_retry=64), dict(team_retry=1),
+               dict(team_retry=16), dict(refill_min=4), dict(refill_min=16)):
+        run(pipeline=2, tile_order_mode=2, suspend_after=(32, 64), **kw)
+elif exp == "sizes":
+    for W, H in ((640, 360), (960, 540), (2560, 1440), (3840, 2160), (5120, 2880), (7680, 4320)):
+        run(W=W, H=H, repeats=3, warmup=1, pipeline=1)
+        run(W=W, H=H, repeats=3, warmup=1, pipeline=1, suspend_after=(-1, -1))
+        for b in ((16, 48), (32, 64), (48, 96)):
+            run(W=W, H=H, repeats=3, warmup=1, pipeline=2, tile_order_mode=2, suspend_after=b)
+elif exp == "strategies":
+    for kid in range(11):
+        run(kid=kid, repeats=3, warmup=1, pipeline=1)
+        for b in ((16, 48), (8, 24), (32, 64)):
+            run(kid=kid, repeats=3, warmup=1, pipeline=2, tile_order_mode=2, suspend_after=b)
