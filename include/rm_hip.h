@@ -137,8 +137,9 @@ typedef struct RmFrameDesc {
      *   queue_refill_min idle lanes a producer wave needs before it looks at queue 0
      *   queue_retry      turns between two looks of a producer wave whose lanes stay idle
      *   team_retry       evaluations between two looks of a team that still carries rays
-     *   age_priority     > 0: a producer wave raises its issue priority to (trips of its oldest ray) / age_priority
-     *                    (capped at 2), so waves carrying old rays win the SIMD they share */
+     *   age_priority     (every launch structure) > 0: a wave raises its issue priority (s_setprio) to
+     *                    (trips of its oldest ray) / age_priority, capped at 3, so the waves that carry the frame's
+     *                    longest chains win the SIMD they share with waves of short rays; results unchanged */
     int32_t pipeline;
     int32_t team_grid;
     int32_t queue_first;

@@ -184,6 +184,7 @@ int make_args(const RmFrameDesc* d, float* depth, int32_t* iters, uint8_t* hit, 
     a->hist_bins = rm::kHistBins;
     // one trip per turn pays where the trip count varies (Mandelbulb); the one-trip union scenes run whole evaluations
     a->interleave = d->eval_mode == 2 || (d->eval_mode == 0 && d->scene_id == 10);
+    a->age_prio = d->age_priority > 0 ? d->age_priority : 0;
     if (d->band_rows > 0 && d->band_stride > 1) {
         a->band_rows = d->band_rows; a->band_stride = d->band_stride; a->band_offset = d->band_offset;
     }
@@ -443,18 +444,22 @@ int launch_frame(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, h
         if (sc->occupancy_pipeline(d->strategy_id, a.interleave, a.frames != nullptr, &per_cu) != hipSuccess || per_cu <= 0) per_cu = 2;
         per_cu = std::min(per_cu, 3);
         const long long resident = (long long)g.prop.multiProcessorCount * per_cu;
-        const long long max_pwgs = ((long long)ntiles + rm::kPipeWaves - 1) / rm::kPipeWaves;
+        // producers and teams wait for one another (bounded), so the grid never exceeds what is resident at once.
+        // A team workgroup also carries kSharedProducers producer waves when rm::kTeamShare (rm_pipeline.h).
+        const long long team_pw = rm::kTeamShare ? rm::kSharedProducers : 0;      // producer waves of a team workgroup
         long long team_wgs = 0;
         if (teams) {
-            // default: a quarter of the resident workgroups (1080p Mandelbulb: 128 of 512; measured)
-            team_wgs = d->team_grid > 0 ? d->team_grid : std::max<long long>(1, resident / 4);
-            team_wgs = std::min<long long>(team_wgs, std::max<long long>(1, resident / 2));
+            // default: a quarter of the resident workgroups are teams (1080p Mandelbulb: 128 of 512; 64 / 96 / 192 measured
+            // 10.0-11.5 / 10.6-11.1 / 10.4-11.5 ms against 9.6-10.0)
+            team_wgs = d->team_grid > 0 ? d->team_grid : std::max<long long>(1, resident / (rm::kTeamShare ? 2 : 4));
+            team_wgs = std::min<long long>(team_wgs, std::max<long long>(1, rm::kTeamShare ? resident : resident / 2));
         }
-        // producers and teams wait for one another (bounded), so the grid never exceeds what is resident at once
-        long long pwgs = d->grid_waves > 0 ? (d->grid_waves + rm::kPipeWaves - 1) / rm::kPipeWaves : resident - team_wgs;
-        pwgs = std::max<long long>(1, std::min<long long>(std::min<long long>(pwgs, max_pwgs), resident - team_wgs));
+        const long long want_pw = d->grid_waves > 0 ? d->grid_waves : (long long)resident * rm::kPipeWaves;   // producer waves asked for
+        long long pure = (std::min<long long>(want_pw, ntiles) - team_wgs * team_pw + rm::kPipeWaves - 1) / rm::kPipeWaves;
+        pure = std::max<long long>(team_pw > 0 && team_wgs > 0 ? 0 : 1, std::min<long long>(pure, resident - team_wgs));
+        const long long pwgs = pure;
         a.team_wgs = (int32_t)team_wgs;
-        a.producer_waves = (int32_t)(pwgs * rm::kPipeWaves);
+        a.producer_waves = (int32_t)(team_wgs * team_pw + pure * rm::kPipeWaves);
         a.suspend_after2 = teams ? park[1] : 0;
         {
             int rc2;
@@ -472,7 +477,6 @@ int launch_frame(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, h
         a.q0_retry = d->queue_retry > 0 ? d->queue_retry : 16;
         a.team_retry = d->team_retry > 0 ? d->team_retry : 4;
         a.team_steal = d->team_steal == 0 ? 1 : (d->team_steal == 1 ? 1 : 0);
-        a.age_prio = d->age_priority > 0 ? d->age_priority : 0;
         a.max_spins = 50000;      // ~50 ms of polling: only reached when part of the grid is not resident
         if (a.tile_cost) HIP_TRY(hipMemsetAsync(a.tile_cost, 0, (size_t)ntiles * 4, s));   // resumed rays may report before the tile flush
         if (d->tile_order_mode == 0) {

@@ -148,17 +148,32 @@ __device__ __forceinline__ void rm_load_tables()
 {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(RM_TABLES_IN_LDS)
     constexpr unsigned tb = SceneTables<Scene>::value;
+    // re-laid-out mirrors (odd row strides, rm_tables.h)
     if constexpr (tb & TB_POW) {
-        copy_table(rm_s_pow_log_tab, rm_g_pow_log_tab, 512);
-        copy_table(rm_s_exp_tab, rm_g_exp_tab, 256);
+        for (int i = threadIdx.x; i < 128 * kPowLogStride; i += blockDim.x) {
+            const int row = i / kPowLogStride, f = i - row * kPowLogStride;
+            rm_s_pow_log_tab[i] = rm_g_pow_log_tab[4 * row + (f ? f + 1 : 0)];
+        }
+        for (int i = threadIdx.x; i < 128 * kExpStride; i += blockDim.x) {
+            const int row = i / kExpStride, f = i - row * kExpStride;
+            rm_s_exp_tab[i] = f < 2 ? rm_g_exp_tab[2 * row + f] : 0ull;
+        }
     }
-    if constexpr (tb & TB_SINCOS) copy_table(rm_s_sincostab, rm_g_sincostab, 440);
+    if constexpr (tb & TB_SINCOS)
+        for (int i = threadIdx.x; i < 110 * kSinCosStride; i += blockDim.x) {
+            const int row = i / kSinCosStride, f = i - row * kSinCosStride;
+            rm_s_sincostab[i] = f < 4 ? rm_g_sincostab[4 * row + f] : 0.0;
+        }
     if constexpr (tb & TB_ACOS) {
         copy_table(rm_s_asncs, rm_g_asncs, 2808);
         copy_table(rm_s_inroot, rm_g_inroot, 128);
     }
     if constexpr (tb & TB_ATAN) copy_table(rm_s_cij, rm_g_cij, 1687);
-    if constexpr (tb & TB_LOG) copy_table(rm_s_log_tab, rm_g_log_tab, 256);
+    if constexpr (tb & TB_LOG)
+        for (int i = threadIdx.x; i < 128 * kLogStride; i += blockDim.x) {
+            const int row = i / kLogStride, f = i - row * kLogStride;
+            rm_s_log_tab[i] = f < 2 ? rm_g_log_tab[2 * row + f] : 0.0;
+        }
     __syncthreads();
 #endif
 }
@@ -331,6 +346,8 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
     // wave-uniform: the scheduler (flush + refill) has something to look at -- a ray finished, a
     // refill handed out pixels or opened a tile.  Otherwise a turn goes straight to the SDF.
     bool dirty = true;
+    int prio_level = 0;                           // current s_setprio level of this wave (age_prio)
+    int since_sched = 0;                          // turns since the scheduler last ran
 
     for (;;) {
         if (dirty) {
@@ -475,6 +492,21 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
                 dirty = true;
             }
         }
+        // issue priority by age: a frame ends with its longest ray, and that ray's wave shares its SIMD with waves full
+        // of short rays for most of the frame.  A wave raises its priority with the trip count of its oldest ray
+        // (throughput-neutral: the other waves get the slots a dependent chain leaves free anyway).
+        if (a.age_prio > 0) {
+            int age = active ? s.i : 0;
+            for (int off = 32; off > 0; off >>= 1) age = max(age, __shfl_xor(age, off));
+            const int lvl = age / a.age_prio;
+            if (lvl != prio_level) {
+                prio_level = lvl;
+                if (lvl <= 0) __builtin_amdgcn_s_setprio(0);
+                else if (lvl == 1) __builtin_amdgcn_s_setprio(1);
+                else if (lvl == 2) __builtin_amdgcn_s_setprio(2);
+                else __builtin_amdgcn_s_setprio(3);
+            }
+        }
         }   // dirty
 
         // ---- 3. exit / idle turn ---------------------------------------------------------------------
@@ -527,6 +559,8 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
             dirty = true;
         }
         }
+        // with age priority on, the scheduler also runs every 16 turns so an ageing ray is noticed without a finish
+        if (a.age_prio > 0 && ++since_sched >= 16) { since_sched = 0; dirty = true; }
         if constexpr (INTERLEAVE) {
             if (active && !ready) ready = Scene::trip(ev);
         }

@@ -22,7 +22,7 @@
 // CPython raises OverflowError for a subnormal result), overflow (+inf).
 #pragma once
 
-#include "rm_libm_tables.h"
+#include "rm_tables.h"
 
 namespace rm {
 
@@ -43,9 +43,9 @@ RM_MATH_HD double rm_pow_log_inline(uint64_t ix, double* tail)
     uint64_t iz = ix - (tmp & 0xfff0000000000000ull);
     double z = rm_asdouble(iz);
     double kd = (double)k;
-    double invc = rm_pow_log_tab[4 * i + 0];
-    double logc = rm_pow_log_tab[4 * i + 2];
-    double logctail = rm_pow_log_tab[4 * i + 3];
+    double invc = tab_pow_log(i, 0);
+    double logc = tab_pow_log(i, 1);
+    double logctail = tab_pow_log(i, 2);
 
     double r = rm_fma(z, invc, -1.0);
     // k*Ln2 + log(c) + r.
@@ -92,10 +92,10 @@ RM_MATH_HD double rm_pow_exp_inline(double ehi, double elo)
     double r = rm_fma(kd, NegLn2hiN, ehi);
     r = rm_fma(kd, NegLn2loN, r);
     r = elo + r;
-    uint32_t idx = 2 * (uint32_t)(ki & 127);
+    const int idx = (int)(ki & 127);
     uint64_t top = ki << 45;
-    double tail = rm_asdouble(rm_exp_tab[idx]);
-    uint64_t sbits = rm_exp_tab[idx + 1] + top;
+    double tail = rm_asdouble(tab_exp(idx, 0));
+    uint64_t sbits = tab_exp(idx, 1) + top;
     double r2 = r * r;
     double a = rm_fma(r, C3, C2);
     double b = rm_fma(r, C5, C4);

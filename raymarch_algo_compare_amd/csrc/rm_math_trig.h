@@ -56,7 +56,7 @@ RM_MATH_HD double rm_taylor_sin(double x, double dx)
 RM_MATH_HD int rm_sincos_row(double u)
 {
     uint32_t i = (uint32_t)rm_asuint64(u);
-    return (int)((i > 109u) ? 0u : i) * 4;
+    return (int)((i > 109u) ? 0u : i);
 }
 
 // do_sin(x, dx), branch-free: Taylor below 0.126, table otherwise (both evaluated, one selected)
@@ -69,7 +69,7 @@ RM_MATH_HD double rm_do_sin(double a, double da)
     const double u = K::big + aa;
     const double x = aa - (u - K::big);
     const int k = rm_sincos_row(u);
-    const double sn = rm_sincostab[k], ssn = rm_sincostab[k + 1], cs = rm_sincostab[k + 2], ccs = rm_sincostab[k + 3];
+    const double sn = tab_sincos(k, 0), ssn = tab_sincos(k, 1), cs = tab_sincos(k, 2), ccs = tab_sincos(k, 3);
     const double xx = x * x;
     const double s = x + rm_fma(x * xx, rm_fma(xx, K::sn5, K::sn3), dx);
     const double c = rm_fma(x, dx, xx * rm_fma(xx, rm_fma(xx, K::cs6, K::cs4), K::cs2));
@@ -86,7 +86,7 @@ RM_MATH_HD double rm_do_cos(double a, double da)
     const double u = K::big + aa;
     const double x = (aa - (u - K::big)) + dx;
     const int k = rm_sincos_row(u);
-    const double sn = rm_sincostab[k], ssn = rm_sincostab[k + 1], cs = rm_sincostab[k + 2], ccs = rm_sincostab[k + 3];
+    const double sn = tab_sincos(k, 0), ssn = tab_sincos(k, 1), cs = tab_sincos(k, 2), ccs = tab_sincos(k, 3);
     const double xx = x * x;
     const double s = rm_fma(x * xx, rm_fma(xx, K::sn5, K::sn3), x);
     const double c = xx * rm_fma(xx, rm_fma(xx, K::cs6, K::cs4), K::cs2);
@@ -197,7 +197,7 @@ RM_MATH_HD double rm_log(double x)
     int i = (int)((tmp >> 45) & 127);
     int k = (int)((int64_t)tmp >> 52);
     uint64_t iz = ix - (tmp & 0xfff0000000000000ull);
-    double invc = rm_log_tab[2 * i], logc = rm_log_tab[2 * i + 1];
+    double invc = tab_log(i, 0), logc = tab_log(i, 1);
     double z = rm_asdouble(iz);
     double r = rm_fma(z, invc, -1.0);
     double kd = (double)k;

@@ -175,13 +175,23 @@ __device__ __forceinline__ void element_pixel(const KernelArgs& a, uint32_t gi, 
                          : a.row0 + y;
 }
 
-// Workgroup shape of the pipeline kernel.  256-thread workgroups, two per compute unit: a team workgroup (three
-// waves, the fourth exits) shares its CU with a producer workgroup.  Measured alternatives at 1080p Mandelbulb /
-// Standard: 512-thread workgroups, one per CU, a team alone on its CU runs its chains at the
-// speed of an idle CU but 48-96 such CUs cannot absorb the rays that cross the threshold (11.1-11.5 ms against
-// 9.6); two barrier-free teams per 512-thread workgroup (waves {0,1,2} and {3,5,6}, LDS arrival counters) doubled
-// the teams and measured 11.4-12.0 ms.  Both shapes stay selectable here (kPipeWaves 8 / kTeamsPerWG 1 or 2).
+// Workgroup shape of the pipeline kernel (1080p Mandelbulb / Standard figures):
+//  kPipeWaves 4, kTeamShare false   256-thread workgroups, two per compute unit: a team workgroup (three waves, the
+//        fourth exits) shares its CU -- and every one of its SIMDs -- with a producer workgroup: 9.6-10.0 ms.
+//  kPipeWaves 8, kTeamsPerWG 1 | 2, kTeamShare false   512-thread workgroups, one per CU, of which `team_grid` carry
+//        one or two teams and nothing else: chains at the speed of an idle CU (13 us per evaluation against 17-20
+//        next to producers), but 48-96 such CUs cannot absorb the rays that cross the threshold: 11.1-12.0 ms.
+//  kPipeWaves 8, kTeamShare true    512-thread workgroups, one per CU; a team workgroup is waves {0,1,2} = the team,
+//        wave 4 exits and waves {3,5,6,7} are producers.  Waves i and i + 4 of a workgroup share a SIMD, so the team's
+//        critical wave (part 0: length -> divide -> acos -> sincos, the longest dependent chain of a trip) has its
+//        SIMD to itself while the compute unit still renders tiles with four waves: 10.2-10.4 ms -- no better, so
+//        what holds the longest rays back next to producers is not the issue slot they share.  The marks
+//        (rm_get_pass_ms) say what is: when the producers are done the longest ray still has > 400 of its 464 team
+//        evaluations ahead -- it sat in queue 1 behind the burst of rays that cross the threshold while the object's
+//        tiles are rendered (90 000 at 48 trips, of which 133 run to 512 and nothing tells them apart).
+// The first shape is built: it is the simplest and measured best.
 constexpr int kPipeWaves = 4;
+constexpr bool kTeamShare = false;
 
 // Role-specific LDS of the pipeline kernel (one allocation: a workgroup has exactly one role).
 template <int TILE_PIX>
@@ -195,6 +205,9 @@ struct PipeProducerLds {
 // use s_barrier (it spans the workgroup): a team then synchronises through an arrival counter in its own LDS block.
 constexpr int kTeamsPerWG = 1;
 static_assert(kTeamsPerWG == 1 || kPipeWaves == 8, "two teams need a 512-thread workgroup");
+static_assert(!kTeamShare || (kPipeWaves == 8 && kTeamsPerWG == 1), "a shared team workgroup is 3 team + 1 idle + 4 producer waves");
+// producer waves of a team workgroup when it is shared, and their rank among them
+constexpr int kSharedProducers = 4;
 struct PipeTeamLds {
     TeamXch xch;
     unsigned int hist[kHistBins];
@@ -206,7 +219,7 @@ struct PipeTeamLds {
 // its arrival is counted; `epoch` is the arrival count this barrier waits for (same value in the team's three waves).
 __device__ __forceinline__ void team_barrier(PipeTeamLds& L, unsigned int& epoch)
 {
-    if constexpr (kTeamsPerWG == 1) {        // one team per workgroup: the hardware barrier (it counts live waves only)
+    if constexpr (kTeamsPerWG == 1 && !kTeamShare) {   // the team is alone in its workgroup: the hardware barrier (it counts live waves only)
         __syncthreads();
         return;
     }
@@ -264,7 +277,9 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
     using Entry = QEntry<Strat>;
     using PLds = PipeProducerLds<TILE_PIX>;
     constexpr size_t kTeamBytes = sizeof(PipeTeamLds) * kTeamsPerWG;
-    constexpr size_t kRoleBytes = sizeof(PLds) > kTeamBytes ? sizeof(PLds) : kTeamBytes;
+    // a workgroup has one role (producer staging and team block overlap) unless team workgroups also render tiles
+    constexpr size_t kRoleBytes = kTeamShare ? sizeof(PLds) + kTeamBytes : (sizeof(PLds) > kTeamBytes ? sizeof(PLds) : kTeamBytes);
+    constexpr size_t kTeamOffset = kTeamShare ? sizeof(PLds) : 0;
     __shared__ __attribute__((aligned(16))) unsigned char s_role[kRoleBytes];
     __shared__ unsigned int s_hist[kHistBins];
 
@@ -276,9 +291,15 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
     if (threadIdx.x == 0) atomicMax(&a.stats[kWMarkStart], ~realtime());
 
     WaveAcc acc;
-    const bool team_role = TEAMS && (int)blockIdx.x < a.team_wgs;
-    if (team_role) {                         // wave-uniform, workgroup-uniform
-        PipeTeamLds* const T = reinterpret_cast<PipeTeamLds*>(s_role);
+    const bool team_wg = TEAMS && (int)blockIdx.x < a.team_wgs;      // workgroup-uniform
+    // wave roles in a team workgroup: 0..2 = part of team 0 (3..5: team 1), -1 = leave, -2 = producer
+    constexpr int kRoleAlone[8] = { 0, 1, 2, kTeamsPerWG > 1 ? 3 : -1, -1, kTeamsPerWG > 1 ? 4 : -1, kTeamsPerWG > 1 ? 5 : -1, -1 };
+    constexpr int kRoleShared[8] = { 0, 1, 2, -2, -1, -2, -2, -2 };
+    constexpr int kProducerRank[8] = { 0, 0, 0, 0, 0, 1, 2, 3 };     // among the producer waves of a shared team workgroup
+    const int wave_role = !team_wg ? -2 : (kTeamShare ? kRoleShared[wave & 7] : kRoleAlone[wave & 7]);
+    const bool team_role = team_wg && wave_role >= 0;
+    if (team_wg) {
+        PipeTeamLds* const T = reinterpret_cast<PipeTeamLds*>(s_role + kTeamOffset);
         for (int t = 0; t < kTeamsPerWG; ++t) {
             for (int b = threadIdx.x; b < kHistBins; b += blockDim.x) T[t].hist[b] = 0u;
             if (threadIdx.x == 0) { T[t].bar = 0u; T[t].base = T[t].count = T[t].queue = T[t].done = 0u; }
@@ -287,17 +308,14 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
     }
 
     if constexpr (TEAMS) {
+    if (team_wg && wave_role == -1) return;     // the wave that would share a SIMD with a team's critical wave
     if (team_role) {
         // =================================== TEAM ====================================================
-        // waves {0,1,2} -> team 0 parts 0..2, waves {3,5,6} -> team 1 parts 0..2, waves 4 and 7 leave
-        constexpr int kTeamOf[8] = { 0, 0, 0, kTeamsPerWG > 1 ? 1 : -1, -1, kTeamsPerWG > 1 ? 1 : -1, kTeamsPerWG > 1 ? 1 : -1, -1 };
-        constexpr int kPartOf[8] = { 0, 1, 2, 0, -1, 1, 2, -1 };
-        const int team = kTeamOf[wave];
-        if (team < 0) return;
+        const int team = wave_role / kTeam;
         // a team carries the frame's critical chains: its waves win the issue arbitration on the SIMDs they share
         __builtin_amdgcn_s_setprio(3);
-        PipeTeamLds& L = reinterpret_cast<PipeTeamLds*>(s_role)[team];
-        const int part = kPartOf[wave];
+        PipeTeamLds& L = reinterpret_cast<PipeTeamLds*>(s_role + kTeamOffset)[team];
+        const int part = wave_role % kTeam;
         unsigned int epoch = 0;               // this team's barrier count (identical in its three waves)
         bool active = false;
         uint32_t my_gi = 0;
@@ -404,7 +422,10 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
     float (*const s_depth)[TILE_PIX] = L.depth[wave];
     uint32_t (*const s_ih)[TILE_PIX] = L.ih[wave];
     const int ntiles = a.tiles_per_frame * a.nframes;
-    const int pwg = (int)blockIdx.x - (TEAMS ? a.team_wgs : 0);        // index among the producer workgroups
+    // this wave's index among the launch's producer waves (its first tile)
+    const int team_wgs = TEAMS ? a.team_wgs : 0;
+    const int pwave = (kTeamShare && team_wg) ? (int)blockIdx.x * kSharedProducers + kProducerRank[wave & 7]
+                                              : (kTeamShare ? team_wgs * kSharedProducers : 0) + ((int)blockIdx.x - team_wgs) * kPipeWaves + wave;
     const int park0 = a.suspend_after;                                   // fresh rays -> queue 0
     const int park1 = (TEAMS && a.team_wgs > 0) ? a.suspend_after2 : 0;  // resumed rays -> queue 1 (teams)
     const bool queues = park0 > 0;
@@ -550,7 +571,7 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
                 if (f >= 0) {
                     int tile = 0;
                     if (first_tile) {
-                        tile = pwg * kPipeWaves + wave;
+                        tile = pwave;
                         first_tile = false;
                     } else {
                         if (lane == 0) tile = (int)atomicAdd(ctl(a, kCTile), 1ull) + a.producer_waves;
@@ -749,8 +770,12 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
         add_after_drain(ctl(a, kCProdExited), 1ull);                           // after this wave's last push
         atomicMax(&a.stats[kWMarkProd], realtime());
     }
-    __syncthreads();
-    for (int b = threadIdx.x; b < kHistBins; b += blockDim.x) {
+    __syncthreads();      // (in a shared team workgroup this also waits for the team waves to have left)
+    // the producer waves of this workgroup flush its histogram between them
+    const bool shared_wg = kTeamShare && team_wg;
+    const int fl_rank = shared_wg ? kProducerRank[wave & 7] * 64 + lane : (int)threadIdx.x;
+    const int fl_stride = shared_wg ? kSharedProducers * 64 : (int)blockDim.x;
+    for (int b = fl_rank; b < kHistBins; b += fl_stride) {
         const unsigned int c = s_hist[b];
         if (c) atomicAdd(&part[kStatsHead + b], (unsigned long long)c);
     }

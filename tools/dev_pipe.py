@@ -31,7 +31,20 @@ def run(sid=10, kid=0, W=1920, H=1080, repeats=7, warmup=2, **tuning):
 
 
 exp = sys.argv[1] if len(sys.argv) > 1 else "first"
-if exp == "tune":
+if exp == "share":
+    run(pipeline=1, tile_order_mode=2)
+    for tg in (64, 96, 128, 160, 192, 256):
+        for b in ((16, 48), (32, 48), (32, 64)):
+            run(pipeline=2, suspend_after=b, team_grid=tg)
+    run(pipeline=2)
+    run(pipeline=2, tile_order_mode=1)
+elif exp == "cheap":
+    for sid in (0, 2, 9, 12, 1, 13, 16, 5, 3):
+        for kid in (0, 4):
+            run(sid=sid, kid=kid)
+            for ap in (8, 16, 32, 64):
+                run(sid=sid, kid=kid, age_priority=ap)
+elif exp == "tune":
     run(pipeline=1, tile_order_mode=2)
     base = dict(pipeline=2, tile_order_mode=2, team_grid=128)
     for b in ((16, 48), (32, 48), (24, 56), (32, 64)):

@@ -151,22 +151,7 @@ def main():
         names = _re.findall(r"RM_TAB (double|uint64_t) (rm_\w+)\[(\d+)\]", body)
         body = _re.sub(r"RM_TAB (double|uint64_t) rm_(\w+)\[", r"RM_TAB \1 rm_g_\2[", body)
         f.write(body)
-        # Gathered (per-lane indexed) tables can be mirrored in LDS by the kernels: with
-        # RM_TABLES_IN_LDS defined, device code reads rm_s_* (filled by rm_load_tables, rm_kernels.h).
-        gathered = [n for n in names if not n[1].endswith("_head")]
-        f.write("\n// ---- table access: global constant memory, or the LDS mirror inside the render kernels ----\n")
-        f.write("#if defined(__HIP_DEVICE_COMPILE__) && defined(RM_TABLES_IN_LDS)\n")
-        for ty, nm, cnt in gathered:
-            f.write(f"__shared__ {ty} rm_s_{nm[3:]}[{cnt}];\n")
-        for ty, nm, cnt in gathered:
-            f.write(f"#define {nm} rm_s_{nm[3:]}\n")
-        f.write("#else\n")
-        for ty, nm, cnt in gathered:
-            f.write(f"#define {nm} rm_g_{nm[3:]}\n")
-        f.write("#endif\n")
-        for ty, nm, cnt in names:
-            if nm.endswith("_head"):
-                f.write(f"#define {nm} rm_g_{nm[3:]}\n")
+        # table access (constant memory or the padded LDS mirrors of the kernels): csrc/rm_tables.h
         f.write("\n")
     print("wrote", OUT)
 

@@ -7,7 +7,8 @@ from collections import defaultdict
 
 
 def short(name):
-    for k in ("render_kernel", "resume_team_kernel", "resume_kernel", "block_var_kernel", "order_tiles_kernel"):
+    for k in ("pipeline_kernel", "render_kernel", "resume_team_kernel", "resume_kernel", "block_var_kernel", "order_tiles_kernel",
+              "stats_reduce_kernel"):
         if k in name:
             return k
     return None
