@@ -280,6 +280,9 @@ int rm_set_queue_capacity(int64_t entries);
 #define RM_MAX_PASSES 4
 int rm_set_pass_timing(int enable);
 int rm_get_pass_ms(void* stream, int32_t* npasses, float* ms);
+/* Single-launch frames: milliseconds after launch of the last push into and the last pop out of queue 1, as decoded
+ * by the latest rm_get_pass_ms (0 when there was none).  A tuning aid: pop long after push = the teams fell behind. */
+int rm_last_queue_marks(float* last_push_ms, float* last_pop_ms);
 
 /* rm_render_batch with an outputs record: depth / iters / hit as above plus the optional frame-major evals map
  * (RmOutputs.evals; t_raw, final_sdf and block_var must be NULL).  With evals, stats[f].sum_evals is filled. */

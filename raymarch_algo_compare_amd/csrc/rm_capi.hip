@@ -97,6 +97,7 @@ struct State {
     int pass_count = 0;
     bool last_was_pipeline = false;                  // rm_get_pass_ms decodes the in-kernel marks of `last_stats`
     const unsigned long long* last_stats = nullptr;
+    float last_push_ms = 0.f, last_pop_ms = 0.f;     // queue-1 marks of the last single-launch frame decoded by rm_get_pass_ms
     uint32_t generation = 0;                         // tag of the queue entries of the latest single-launch frame
     hipEvent_t frame_ev = nullptr;                   // end of the latest frame, on `frame_stream` (frames share one workspace)
     hipStream_t frame_stream = nullptr;
@@ -477,7 +478,8 @@ int launch_frame(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, h
         a.q0_retry = d->queue_retry > 0 ? d->queue_retry : 16;
         a.team_retry = d->team_retry > 0 ? d->team_retry : 4;
         a.team_steal = d->team_steal == 0 ? 1 : (d->team_steal == 1 ? 1 : 0);
-        a.max_spins = 50000;      // ~50 ms of polling: only reached when part of the grid is not resident
+        a.max_spins = 50000;
+        a.team_prio = 3;      // 0 / 1 / 3 measured alike (10.0-10.4 ms): what slows a ray next to producers is not the issue slot      // ~50 ms of polling: only reached when part of the grid is not resident
         if (a.tile_cost) HIP_TRY(hipMemsetAsync(a.tile_cost, 0, (size_t)ntiles * 4, s));   // resumed rays may report before the tile flush
         if (d->tile_order_mode == 0) {
             // Default tile order of the single launch: centre-out (where the camera looks, the object -- and its
@@ -1019,8 +1021,19 @@ int rm_get_pass_ms(void* stream, int32_t* npasses, float* ms)
             const float prod = (float)((double)(w[rm::kWMarkProd] - start) * 1e-5);
             ms[0] = t_tiles; ms[1] = fresh - t_tiles; ms[2] = prod - fresh; ms[3] = std::max(0.f, total - prod);
             *npasses = 4;
+            // times of the last push into / pop out of queue 1 since launch, for tools (rm_last_queue_marks)
+            g.last_push_ms = w[rm::kWMarkPush] >= start ? (float)((double)(w[rm::kWMarkPush] - start) * 1e-5) : 0.f;
+            g.last_pop_ms = w[rm::kWMarkPop] >= start ? (float)((double)(w[rm::kWMarkPop] - start) * 1e-5) : 0.f;
         }
     }
+    return RM_OK;
+}
+
+int rm_last_queue_marks(float* last_push_ms, float* last_pop_ms)
+{
+    if (!last_push_ms || !last_pop_ms) return fail(RM_E_BAD_ARG, "NULL output");
+    *last_push_ms = g.last_push_ms;
+    *last_pop_ms = g.last_pop_ms;
     return RM_OK;
 }
 

@@ -115,6 +115,7 @@ struct KernelArgs {
     int32_t team_retry;         // evaluations between two looks of a team with idle lanes
     int32_t team_steal;         // teams take queue 0 entries while queue 1 is empty
     int32_t max_spins;          // polls after which a producer wave with nothing to do stops waiting for the others
+    int32_t team_prio;          // s_setprio level of the team waves (0..3)
     int32_t age_prio;           // > 0: a producer wave's issue priority = (trips of its oldest ray) / age_prio, capped at 2
 };
 

@@ -59,6 +59,8 @@ constexpr int kWMarkStart = 13;   // ~min s_memrealtime at kernel entry         
 constexpr int kWMarkFresh = 14;   // max s_memrealtime when a wave reported fresh-done } for rm_get_pass_ms
 constexpr int kWMarkProd = 15;    // max s_memrealtime when a producer wave exited  }
 constexpr int kWMarkTiles = 17;   // ~min s_memrealtime when a wave found the tile counter exhausted
+constexpr int kWMarkPush = 18;    // max s_memrealtime of a push into queue 1
+constexpr int kWMarkPop = 19;     // max s_memrealtime of a pop out of queue 1
 constexpr int kWError = 16;       // != 0: a wait of the queue protocol ran into its bound (the host reports RM_E_HIP)
 // No wait in this kernel is unbounded: a protocol bug or a lost workgroup must end in an error code, never in a
 // hung device.  Bounds are far beyond anything a healthy launch reaches.
@@ -160,6 +162,7 @@ __device__ __forceinline__ bool q_push(const KernelArgs& a, int q, bool want, ui
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing lane's entry has left the wave
     if (ok) __hip_atomic_store((uint32_t*)(dst + 1), a.generation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (q == 1 && lane_id() == 0) atomicMax(&a.stats[kWMarkPush], realtime());
     return ok;
 }
 
@@ -313,7 +316,9 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
         // =================================== TEAM ====================================================
         const int team = wave_role / kTeam;
         // a team carries the frame's critical chains: its waves win the issue arbitration on the SIMDs they share
-        __builtin_amdgcn_s_setprio(3);
+        if (a.team_prio >= 3) __builtin_amdgcn_s_setprio(3);
+        else if (a.team_prio == 2) __builtin_amdgcn_s_setprio(2);
+        else if (a.team_prio == 1) __builtin_amdgcn_s_setprio(1);
         PipeTeamLds& L = reinterpret_cast<PipeTeamLds*>(s_role + kTeamOffset)[team];
         const int part = wave_role % kTeam;
         unsigned int epoch = 0;               // this team's barrier count (identical in its three waves)
@@ -352,6 +357,7 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
                         if (!done && now - idle_since > kMaxTeamWaitTicks) { atomicMax(&a.stats[kWError], 2ull); done = 1; }
                     } else if (cnt > 0) {
                         idle_since = 0;
+                        if (q == 1) atomicMax(&a.stats[kWMarkPop], realtime());
                     }
                     L.base = base; L.count = (unsigned int)cnt; L.queue = (unsigned int)q; L.done = done;
                 }
@@ -527,8 +533,11 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
         int nidle = __popcll(idle);
         if (nidle >= a.refill_min || nidle == 64) {
             bool fresh_left = more_tiles || pool_next < TILE_PIX;
-            // parked rays first (q0_first), or only once this wave has no fresh pixels left to hand out
-            if (queues && !detach && (a.q0_first || !fresh_left) && (nidle >= a.q0_refill_min || nidle == 64)) {
+            bool got_parked = false;
+            // Idle lanes go, in this order, to (1) the pixels of the tile this wave has open -- every pixel of an open
+            // tile starts at once, no long ray waits in a pixel pool behind lanes that older rays hold; (2) parked rays
+            // (q0_first: before a NEW tile is opened, oldest work first; else only once no tile is left); (3) the next tile.
+            if (queues && !detach && (a.q0_first ? pool_next >= TILE_PIX : !fresh_left) && (nidle >= a.q0_refill_min || nidle == 64)) {
                 unsigned int base = 0;
                 int cnt = 0;
                 if (lane == 0) cnt = q_claim_lane0(a, 0, nidle, base);
@@ -560,11 +569,12 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
                     }
                     spins = 0;
                     dirty = true;
+                    got_parked = true;
                     idle = __ballot(!active);
                     nidle = __popcll(idle);
                 }
             }
-            if (nidle > 0 && pool_next >= TILE_PIX && more_tiles) {
+            if (nidle > 0 && (!got_parked || nidle >= a.refill_min) && pool_next >= TILE_PIX && more_tiles) {
                 int f = -1;
 #pragma unroll
                 for (int k = kSlots - 1; k >= 0; --k) f = (slot_tile[k] < 0) ? k : f;

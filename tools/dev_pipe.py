@@ -20,10 +20,12 @@ def run(sid=10, kid=0, W=1920, H=1080, repeats=7, warmup=2, **tuning):
     n, ms = ctypes.c_int32(0), (ctypes.c_float * 4)()
     _native.check(L.rm_get_pass_ms(None, ctypes.byref(n), ms))
     _native.check(L.rm_set_pass_timing(0))
+    lp, lq = ctypes.c_float(0), ctypes.c_float(0)
+    _native.check(L.rm_last_queue_marks(ctypes.byref(lp), ctypes.byref(lq)))
     st = out["stats"]
     r = dict(ms=round(out["timing"]["ms_median"], 3), ms_min=round(out["timing"]["ms_min"], 3),
              mrays=round(W * H / out["timing"]["ms_median"] / 1e3, 1), passes=[round(ms[i], 3) for i in range(n.value)],
-             sum_iters=st["sum_iters"], **{k: v for k, v in tuning.items()})
+             q1_last_push_pop=[round(lp.value, 2), round(lq.value, 2)], **{k: v for k, v in tuning.items()})
     if (W, H) != (1920, 1080): r["WxH"] = f"{W}x{H}"
     if (sid, kid) != (10, 0): r["cell"] = f"{scene.name}/{registry.list_strategies()[kid]}"
     print(json.dumps(r), flush=True)
@@ -31,7 +33,19 @@ def run(sid=10, kid=0, W=1920, H=1080, repeats=7, warmup=2, **tuning):
 
 
 exp = sys.argv[1] if len(sys.argv) > 1 else "first"
-if exp == "share":
+if exp == "q0":
+    run(pipeline=2)
+    for qf in (1, 2):
+        for b in ((16, 48), (32, 64), (24, 48), (32, 96), (16, 32)):
+            for tg in (64, 128):
+                run(pipeline=2, suspend_after=b, queue_first=qf, team_grid=tg)
+    for kw in (dict(queue_refill_min=4), dict(queue_refill_min=32), dict(team_steal=2), dict(queue_retry=4), dict(queue_retry=64)):
+        run(pipeline=2, suspend_after=(16, 48), queue_first=1, **kw)
+elif exp == "marks":
+    for tg in (64, 128, 192):
+        for b in ((16, 48), (32, 64), (32, 96), (32, 128)):
+            run(pipeline=2, suspend_after=b, team_grid=tg)
+elif exp == "share":
     run(pipeline=1, tile_order_mode=2)
     for tg in (64, 96, 128, 160, 192, 256):
         for b in ((16, 48), (32, 48), (32, 64)):
