@@ -15,7 +15,9 @@ Workloads (--workload):
   mandelbulb-1080p  (default) every rank renders a full 1920x1080 frame per step: the rays of an
                     N-frame batch are sharded one frame per GPU, no data-path collective (weak scaling).
   rowshard-8k       BASELINE config 5: ONE 7680x4320 frame per step, rows dealt band-cyclically to
-                    the ranks, the three maps all-gathered with RCCL over xGMI (strong scaling).
+                    the ranks, the three maps all-gathered with RCCL over xGMI by the library itself
+                    (rm_gather_frame: ncclAllGather x 3 + device-side row placement; torch.distributed only
+                    launches the ranks and carries the 128-byte communicator id) -- strong scaling.
 
 The timed region holds exactly K steps between barrier + torch.cuda.synchronize(); rank 0 prints
 ONE JSON line.  `roofline` prices the render kernel against HBM (9 algorithmic bytes per ray; the
@@ -147,6 +149,18 @@ def main():
     sptr = ctypes.c_void_p(stream.cuda_stream)
     assert sptr.value, "expected a non-default stream handle"
 
+    full = None
+    if plan is not None and world > 1:
+        # the library's own RCCL communicator (include/rm_hip.h): rank 0 makes the id, torch.distributed ships it
+        ident = ctypes.create_string_buffer(128)
+        if rank == 0:
+            _native.check(L.rm_comm_unique_id(ident))
+        box = [ident.raw]
+        dist.broadcast_object_list(box, src=0)
+        _native.check(L.rm_comm_init(box[0], world, rank))
+        full = (torch.empty((H, W), dtype=torch.float32, device=dev), torch.empty((H, W), dtype=torch.int32, device=dev),
+                torch.empty((H, W), dtype=torch.uint8, device=dev))
+
     def step(ev0=None, ev1=None):
         if ev0 is not None:
             ev0.record(stream)
@@ -155,10 +169,12 @@ def main():
                                          ctypes.c_void_p(d_stats.data_ptr()), sptr))
         if ev1 is not None:
             ev1.record(stream)
-        if plan is not None and world > 1:
-            # the frame's only exchange: RCCL all-gather of the three maps (xGMI), on the same stream
-            return [sharding.all_gather_frame(t, plan) for t in (d_depth, d_iters, d_hit)]
-        return None
+        if full is not None:
+            # the frame's only exchange: RCCL all-gather of the three maps (xGMI) + row placement, on the same stream
+            _native.check(L.rm_gather_frame(ctypes.byref(desc), ctypes.c_void_p(d_depth.data_ptr()), ctypes.c_void_p(d_iters.data_ptr()),
+                                            ctypes.c_void_p(d_hit.data_ptr()), ctypes.c_void_p(full[0].data_ptr()),
+                                            ctypes.c_void_p(full[1].data_ptr()), ctypes.c_void_p(full[2].data_ptr()), sptr))
+        return full
 
     def barrier():
         if world > 1:
@@ -323,6 +339,8 @@ def main():
                 line["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port",
                                         "sample": f"unavailable: {e}"}
         print(json.dumps(line), flush=True)
+    if full is not None:
+        _native.check(L.rm_comm_destroy())
     if world > 1:
         dist.destroy_process_group()
 

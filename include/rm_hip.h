@@ -29,6 +29,7 @@ extern "C" {
 #define RM_E_NO_DEVICE (-4)
 #define RM_E_HIP (-5)
 #define RM_E_BAD_ARG (-6)
+#define RM_E_RCCL (-7)     /* librccl could not be loaded, or one of its calls failed (text in rm_last_error) */
 
 #define RM_NUM_SCENES 20
 #define RM_NUM_STRATEGIES 11
@@ -294,6 +295,37 @@ int rm_alloc_frame(int32_t width, int32_t rows, void** d_depth, void** d_iters, 
 int rm_free_frame(void* d_depth, void* d_iters, void* d_hit);
 int rm_copy_frame_to_host(int32_t width, int32_t rows, const void* d_depth, const void* d_iters,
                           const void* d_hit, float* depth, int32_t* iters, uint8_t* hit);
+
+/* ---- BASELINE config 5: one frame row-sharded over the GPUs of a node, one process per GPU ------------------
+ * The frame shards with no exchange while it is rendered (rays are independent); its only communication is the
+ * final gather of the three maps.  These entry points do that gather from C with RCCL over xGMI -- no PyTorch on the
+ * path.  RCCL is loaded on first use (dlopen "librccl.so.1"); the library has no link-time dependency on it.
+ *   rank 0:      rm_comm_unique_id(id);  ship the 128 bytes to the other ranks (any channel: a file, MPI, a socket)
+ *   every rank:  rm_init(local device);  rm_comm_init(id, world_size, rank);
+ *   per frame:   rm_render_device(shard desc, ...);  rm_gather_frame(...)  -> the whole frame on every rank
+ *   at exit:     rm_comm_destroy();
+ * Row plan (the same on every rank; raymarch_algo_compare_amd/sharding.py states it in Python): height a multiple of
+ * 4 * world_size -> band-cyclic, rank r renders the 4-row bands r, r + N, r + 2N ... (RmFrameDesc.band_rows = 4,
+ * band_stride = N, band_offset = r, rows = height / N), so every rank holds the same mix of sky and object rows and
+ * no 8x4 divergence block straddles two ranks; otherwise contiguous 4-aligned blocks of rm_shard_rows() rows (the
+ * last rank takes the remainder). */
+#define RM_COMM_ID_BYTES 128
+int rm_comm_unique_id(uint8_t id[RM_COMM_ID_BYTES]);
+int rm_comm_init(const uint8_t id[RM_COMM_ID_BYTES], int32_t world_size, int32_t rank);
+int rm_comm_destroy(void);
+/* Rows per rank of the contiguous plan: ceil(ceil(height / 4) / world_size) * 4. */
+int32_t rm_shard_rows(int32_t height, int32_t world_size);
+/* All-gather the local shard (RmFrameDesc.rows x width elements per map, device pointers, as rm_render_device left
+ * them) from every rank -- three ncclAllGather on `stream` (NULL = the library stream) -- and put the rows in image
+ * order: d_full_* hold height x width elements on every rank.  `shard` is the descriptor the shard was rendered
+ * with.  Asynchronous on the stream. */
+int rm_gather_frame(const RmFrameDesc* shard, const void* d_depth, const void* d_iters, const void* d_hit,
+                    void* d_full_depth, void* d_full_iters, void* d_full_hit, void* stream);
+/* The second half of rm_gather_frame on its own: `d_gathered` holds the shards of all ranks one after the other
+ * (rank-major, rows_per_rank x width elements of elem_bytes each, as ncclAllGather leaves them); writes the
+ * height x width image.  cyclic != 0: band-cyclic plan with 4-row bands; else contiguous blocks.  Asynchronous. */
+int rm_assemble_frame(int32_t world_size, int32_t height, int32_t width, int32_t rows_per_rank, int32_t cyclic,
+                      int32_t elem_bytes, const void* d_gathered, void* d_full, void* stream);
 
 /* Store-path probe: writes the 9 B/ray outputs with the render kernel's flush code and no
  * marching, to measure the isolated HBM write bandwidth of the path. */

@@ -19,7 +19,7 @@ RM_HIST_BINS = 544
 RM_MAX_TIMED = 256
 
 ERROR_NAMES = {0: "RM_OK", -1: "RM_E_BAD_SCENE", -2: "RM_E_BAD_STRATEGY", -3: "RM_E_BAD_DIMS",
-               -4: "RM_E_NO_DEVICE", -5: "RM_E_HIP", -6: "RM_E_BAD_ARG"}
+               -4: "RM_E_NO_DEVICE", -5: "RM_E_HIP", -6: "RM_E_BAD_ARG", -7: "RM_E_RCCL"}
 
 EXPORTS = [
     "rm_init", "rm_shutdown", "rm_last_error", "rm_device_info", "rm_num_scenes", "rm_num_strategies",
@@ -27,6 +27,7 @@ EXPORTS = [
     "rm_sdf_eval", "rm_march_rays", "rm_march_rays_team", "rm_render", "rm_render_outputs", "rm_render_device", "rm_stats_device_bytes",
     "rm_read_stats", "rm_bench_device", "rm_alloc_frame", "rm_free_frame", "rm_copy_frame_to_host",
     "rm_bench_store_path", "rm_render_batch", "rm_render_batch_outputs", "rm_set_pass_timing", "rm_get_pass_ms", "rm_last_queue_marks", "rm_set_queue_capacity",
+    "rm_comm_unique_id", "rm_comm_init", "rm_comm_destroy", "rm_shard_rows", "rm_gather_frame", "rm_assemble_frame",
 ]
 
 
@@ -177,6 +178,11 @@ def load() -> ctypes.CDLL:
         L.rm_set_queue_capacity.argtypes = [ctypes.c_int64]
         L.rm_get_pass_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_float)]
         L.rm_last_queue_marks.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+        L.rm_comm_unique_id.argtypes = [ctypes.c_char_p]
+        L.rm_comm_init.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32]
+        L.rm_shard_rows.argtypes = [ctypes.c_int32, ctypes.c_int32]
+        L.rm_gather_frame.argtypes = [ctypes.POINTER(RmFrameDesc), vp, vp, vp, vp, vp, vp, vp]
+        L.rm_assemble_frame.argtypes = [ctypes.c_int32] * 6 + [vp, vp, vp]
         for name in EXPORTS:
             if name not in ("rm_shutdown", "rm_last_error", "rm_stats_device_bytes", "rm_default_strategy_params"):
                 getattr(L, name).restype = ctypes.c_int

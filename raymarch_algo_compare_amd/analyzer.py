@@ -1,10 +1,14 @@
-"""Cross-run matrix / CSV writer with the reference's schema (metrics/analyzer.py:22-169):
-rows = scene names in first-seen order, columns = sorted strategy short names, one
-matrix_<metric>.csv per metric, pandas default float formatting, NaN -> empty."""
+"""Cross-run result table and the nine `matrix_<metric>.csv` files of a run.
+
+File names, row / column order and number formatting are the reference's CSV schema (its example/ directory;
+metrics/analyzer.py:153-169 writes them): one CSV per metric, rows = scenes in the order they were first rendered,
+columns = strategy short names in sorted order, floats as pandas prints them, a missing cell left empty.  The table
+itself is kept as a mapping (scene, strategy) -> RayMarchStats filled as results arrive.
+"""
 from __future__ import annotations
 
 import os
-from typing import List, Optional, Tuple
+from typing import Dict, Iterable, List, Optional, Tuple
 
 import numpy as np
 
@@ -18,45 +22,51 @@ CSV_METRICS = [
 
 
 class MetricsAnalyzer:
+    """Collects one RayMarchStats per (scene, strategy) cell; the first result of a cell wins, like a linear search
+    over the arrival order would."""
+
     def __init__(self):
-        self.all_stats: List[RayMarchStats] = []
+        self.all_stats: List[RayMarchStats] = []                       # arrival order (the CLI's --json summary walks it)
+        self._cells: Dict[Tuple[str, str], RayMarchStats] = {}
+        self._scene_order: Dict[str, int] = {}                          # scene name -> rank of first appearance
 
-    def add_result(self, stats: RayMarchStats):
+    # -- filling ---------------------------------------------------------------------------------------------
+    def add_result(self, stats: RayMarchStats) -> None:
         self.all_stats.append(stats)
+        self._cells.setdefault((stats.scene_name, stats.strategy_name), stats)
+        self._scene_order.setdefault(stats.scene_name, len(self._scene_order))
 
-    def add_results(self, stats_list: List[RayMarchStats]):
-        self.all_stats.extend(stats_list)
+    def add_results(self, stats_list: Iterable[RayMarchStats]) -> None:
+        for st in stats_list:
+            self.add_result(st)
+
+    # -- axes --------------------------------------------------------------------------------------------------
+    def get_scenes(self) -> List[str]:
+        return sorted(self._scene_order, key=self._scene_order.__getitem__)
 
     def get_strategies(self) -> List[str]:
-        return sorted(set(s.strategy_name for s in self.all_stats))
-
-    def get_scenes(self) -> List[str]:
-        seen: List[str] = []
-        for s in self.all_stats:
-            if s.scene_name not in seen:
-                seen.append(s.scene_name)
-        return seen
+        return sorted({strategy for _, strategy in self._cells})
 
     def get_stat(self, strategy: str, scene: str) -> Optional[RayMarchStats]:
-        for s in self.all_stats:
-            if s.strategy_name == strategy and s.scene_name == scene:
-                return s
-        return None
+        return self._cells.get((scene, strategy))
 
+    # -- tables ------------------------------------------------------------------------------------------------
     def per_scene_matrix(self, metric: str = "iteration_mean") -> Tuple[List[str], List[str], np.ndarray]:
-        scenes, strategies = self.get_scenes(), self.get_strategies()
-        matrix = np.full((len(scenes), len(strategies)), np.nan)
-        for si, scene in enumerate(scenes):
-            for sti, strategy in enumerate(strategies):
-                stat = self.get_stat(strategy, scene)
-                if stat:
-                    v = getattr(stat, metric, np.nan)
-                    matrix[si, sti] = np.nan if v is None else v
-        return scenes, strategies, matrix
+        """(scene names, strategy names, values[scene, strategy]); NaN where a cell is missing or the metric is unset."""
+        rows, cols = self.get_scenes(), self.get_strategies()
+        row_of = {name: i for i, name in enumerate(rows)}
+        col_of = {name: j for j, name in enumerate(cols)}
+        table = np.full((len(rows), len(cols)), np.nan)
+        for (scene, strategy), st in self._cells.items():
+            value = getattr(st, metric, None)
+            if value is not None:
+                table[row_of[scene], col_of[strategy]] = value
+        return rows, cols, table
 
-    def save_csv_matrices(self, output_dir: str):
+    def save_csv_matrices(self, output_dir: str) -> None:
         import pandas as pd
         os.makedirs(output_dir, exist_ok=True)
         for metric in CSV_METRICS:
-            scenes, strategies, matrix = self.per_scene_matrix(metric)
-            pd.DataFrame(matrix, index=scenes, columns=strategies).to_csv(os.path.join(output_dir, f"matrix_{metric}.csv"))
+            rows, cols, table = self.per_scene_matrix(metric)
+            frame = pd.DataFrame(table, index=rows, columns=cols)
+            frame.to_csv(os.path.join(output_dir, f"matrix_{metric}.csv"))

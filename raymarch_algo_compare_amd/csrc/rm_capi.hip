@@ -4,6 +4,8 @@
 // (scene, strategy) -> kernel dispatch.  No CPU implementation of the path exists in
 // this library: without a usable gfx950 device every entry point returns an error.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types and prototypes only: the library is loaded with dlopen on first use
 
 #include <algorithm>
 #include <cstdarg>
@@ -605,6 +607,89 @@ int timed_launches(const RmFrameDesc* d, const rm::KernelArgs& a, int tile_h, in
     return RM_OK;
 }
 
+// ---- RCCL, loaded on first use ------------------------------------------------------------
+struct Rccl {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    ncclComm_t comm = nullptr;
+    int world = 0, rank = -1;
+    Buf gather[3], pad[3];      // all-gather landing buffers (rank-major) and padded send buffers of a short last shard
+} R;
+
+int rccl_load()
+{
+    if (R.handle) return RM_OK;
+    void* h = nullptr;
+    for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
+        h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+    }
+    if (!h) return fail(RM_E_RCCL, "librccl.so.1 could not be loaded: %s", dlerror());
+#define RM_SYM(field, sym)                                                                     \
+    R.field = reinterpret_cast<decltype(R.field)>(dlsym(h, #sym));                              \
+    if (!R.field) { dlclose(h); return fail(RM_E_RCCL, "librccl lacks %s", #sym); }
+    RM_SYM(GetUniqueId, ncclGetUniqueId)
+    RM_SYM(CommInitRank, ncclCommInitRank)
+    RM_SYM(CommDestroy, ncclCommDestroy)
+    RM_SYM(AllGather, ncclAllGather)
+    RM_SYM(GroupStart, ncclGroupStart)
+    RM_SYM(GroupEnd, ncclGroupEnd)
+    RM_SYM(GetErrorString, ncclGetErrorString)
+#undef RM_SYM
+    R.handle = h;
+    return RM_OK;
+}
+
+#define RCCL_TRY(expr)                                                                         \
+    do {                                                                                       \
+        ncclResult_t r_ = (expr);                                                              \
+        if (r_ != ncclSuccess)                                                                 \
+            return fail(RM_E_RCCL, "%s failed: %s (%s:%d)", #expr, R.GetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+// Rows of the gathered shards (rank-major) -> image order.  One thread per 16-byte (or 1-byte) piece of a row.
+template <class T>
+__global__ void assemble_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, int world, int height, long long row_elems,
+                                     int rows_per_rank, int cyclic)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= row_elems) return;
+    const int y = blockIdx.y;                          // image row
+    int r, local;
+    if (cyclic) {
+        const int band = y >> 2;                       // 4-row bands dealt round-robin
+        r = band % world;
+        local = (band / world) * 4 + (y & 3);
+    } else {
+        r = y / rows_per_rank;
+        local = y - r * rows_per_rank;
+    }
+    dst[(long long)y * row_elems + i] = src[((long long)r * rows_per_rank + local) * row_elems + i];
+}
+
+int assemble(int world, int height, int width, int rows_per_rank, int cyclic, int elem_bytes, const void* src, void* dst, hipStream_t s)
+{
+    const long long row_bytes = (long long)width * elem_bytes;
+    if (height <= 0 || row_bytes <= 0) return RM_OK;
+    const bool vec = (row_bytes % 16 == 0) && ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0);
+    if (vec) {
+        const long long n = row_bytes / 16;
+        hipLaunchKernelGGL((assemble_rows_kernel<uint4>), dim3((unsigned)((n + 255) / 256), (unsigned)height), dim3(256), 0, s,
+                           (const uint4*)src, (uint4*)dst, world, height, n, rows_per_rank, cyclic);
+    } else {
+        hipLaunchKernelGGL((assemble_rows_kernel<unsigned char>), dim3((unsigned)((row_bytes + 255) / 256), (unsigned)height), dim3(256), 0, s,
+                           (const unsigned char*)src, (unsigned char*)dst, world, height, row_bytes, rows_per_rank, cyclic);
+    }
+    HIP_TRY(hipGetLastError());
+    return RM_OK;
+}
+
 // ---- store-path probe: the flush of render_kernel without the march --------------------
 __global__ __launch_bounds__(64) void store_path_kernel(float* depth, int32_t* iters, uint8_t* hit, int width,
                                                         int rows, int tiles_x, int ntiles)
@@ -971,6 +1056,133 @@ int rm_render_batch_outputs(const RmFrameDesc* shape, int32_t nframes, const dou
                 for (size_t i = 0; i < n; ++i) st.sum_evals += (uint64_t)evals[(size_t)f * n + i];
         }
     }
+    return RM_OK;
+}
+
+int32_t rm_shard_rows(int32_t height, int32_t world_size)
+{
+    if (height <= 0 || world_size <= 0) return 0;
+    const int nblk = (height + 3) / 4;
+    return ((nblk + world_size - 1) / world_size) * 4;
+}
+
+int rm_comm_unique_id(uint8_t id[RM_COMM_ID_BYTES])
+{
+    static_assert(sizeof(ncclUniqueId) == RM_COMM_ID_BYTES, "ncclUniqueId size");
+    if (!id) return fail(RM_E_BAD_ARG, "id is NULL");
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = rccl_load();
+    if (rc) return rc;
+    ncclUniqueId u;
+    RCCL_TRY(R.GetUniqueId(&u));
+    memcpy(id, &u, sizeof u);
+    return RM_OK;
+}
+
+int rm_comm_init(const uint8_t id[RM_COMM_ID_BYTES], int32_t world_size, int32_t rank)
+{
+    int rc = check_ready();
+    if (rc) return rc;
+    if (!id || world_size < 1 || rank < 0 || rank >= world_size) return fail(RM_E_BAD_ARG, "bad communicator arguments");
+    std::lock_guard<std::mutex> lk(g_mu);
+    if ((rc = rccl_load())) return rc;
+    if (R.comm) return fail(RM_E_BAD_ARG, "a communicator exists already; call rm_comm_destroy() first");
+    HIP_TRY(hipSetDevice(g.device));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    RCCL_TRY(R.CommInitRank(&R.comm, world_size, u, rank));
+    R.world = world_size;
+    R.rank = rank;
+    return RM_OK;
+}
+
+int rm_comm_destroy(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!R.comm) return RM_OK;
+    if (g.ready) {
+        (void)hipSetDevice(g.device);
+        (void)hipDeviceSynchronize();
+    }
+    const ncclResult_t r = R.CommDestroy(R.comm);
+    R.comm = nullptr;
+    R.world = 0; R.rank = -1;
+    for (Buf& b : R.gather) b.release();
+    for (Buf& b : R.pad) b.release();
+    if (r != ncclSuccess) return fail(RM_E_RCCL, "ncclCommDestroy failed: %s", R.GetErrorString(r));
+    return RM_OK;
+}
+
+int rm_assemble_frame(int32_t world_size, int32_t height, int32_t width, int32_t rows_per_rank, int32_t cyclic, int32_t elem_bytes,
+                      const void* d_gathered, void* d_full, void* stream)
+{
+    int rc = check_ready();
+    if (rc) return rc;
+    if (world_size < 1 || height < 0 || width <= 0 || rows_per_rank < 0 || (elem_bytes != 1 && elem_bytes != 4 && elem_bytes != 8) ||
+        !d_gathered || !d_full)
+        return fail(RM_E_BAD_ARG, "bad assemble arguments");
+    if (cyclic && (height % (4 * world_size) != 0 || rows_per_rank != height / world_size))
+        return fail(RM_E_BAD_DIMS, "band-cyclic plan needs height %% (4 * world_size) == 0 and rows_per_rank == height / world_size");
+    if (!cyclic && (long long)rows_per_rank * world_size < height) return fail(RM_E_BAD_DIMS, "the shards do not cover the frame");
+    std::lock_guard<std::mutex> lk(g_mu);
+    HIP_TRY(hipSetDevice(g.device));
+    return assemble(world_size, height, width, rows_per_rank, cyclic ? 1 : 0, elem_bytes, d_gathered, d_full,
+                    stream ? (hipStream_t)stream : g.stream);
+}
+
+int rm_gather_frame(const RmFrameDesc* d, const void* d_depth, const void* d_iters, const void* d_hit, void* d_full_depth,
+                    void* d_full_iters, void* d_full_hit, void* stream)
+{
+    int rc = check_ready();
+    if (rc) return rc;
+    if ((rc = check_desc(d))) return rc;
+    if (!d_depth || !d_iters || !d_hit || !d_full_depth || !d_full_iters || !d_full_hit) return fail(RM_E_BAD_ARG, "NULL buffer");
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!R.comm) return fail(RM_E_RCCL, "no communicator: call rm_comm_init() first");
+    HIP_TRY(hipSetDevice(g.device));
+    hipStream_t s = stream ? (hipStream_t)stream : g.stream;
+    const int N = R.world, H = d->height, W = d->width;
+    const bool cyclic = d->band_rows > 0 && d->band_stride > 1;
+    int per;                                       // rows every rank contributes to the collective
+    if (cyclic) {
+        if (d->band_rows != 4 || d->band_stride != N || d->band_offset != R.rank || d->row0 != 0 || H % (4 * N) != 0 || d->rows != H / N)
+            return fail(RM_E_BAD_DIMS, "band-cyclic shard does not match the communicator (4-row bands, stride = world size %d, "
+                                       "offset = rank %d, rows = height / world size)", N, R.rank);
+        per = d->rows;
+    } else {
+        per = rm_shard_rows(H, N);
+        if (N == 1) per = H;
+        const int r0 = std::min(R.rank * per, H), r1 = std::min((R.rank + 1) * per, H);
+        if (d->row0 != r0 || d->rows != r1 - r0)
+            return fail(RM_E_BAD_DIMS, "contiguous shard of rank %d must be rows [%d, %d)", R.rank, r0, r1);
+    }
+    const void* src[3] = { d_depth, d_iters, d_hit };
+    void* dst[3] = { d_full_depth, d_full_iters, d_full_hit };
+    const int eb[3] = { 4, 4, 1 };
+    const void* send[3];
+    for (int k = 0; k < 3; ++k) {
+        const size_t shard_bytes = (size_t)per * W * eb[k];
+        if ((rc = R.gather[k].ensure(shard_bytes * (size_t)N + 16))) return rc;
+        send[k] = src[k];
+        if (d->rows < per) {                        // short last shard of a contiguous plan: pad the send buffer
+            if ((rc = R.pad[k].ensure(shard_bytes + 16))) return rc;
+            HIP_TRY(hipMemsetAsync(R.pad[k].p, 0, shard_bytes, s));
+            if (d->rows > 0) HIP_TRY(hipMemcpyAsync(R.pad[k].p, src[k], (size_t)d->rows * W * eb[k], hipMemcpyDeviceToDevice, s));
+            send[k] = R.pad[k].p;
+        }
+    }
+    // the frame's only exchange: three all-gathers in one group (direct xGMI links between the GPUs of a node)
+    RCCL_TRY(R.GroupStart());
+    for (int k = 0; k < 3; ++k) {
+        const ncclResult_t r = R.AllGather(send[k], R.gather[k].p, (size_t)per * W * eb[k], ncclUint8, R.comm, s);
+        if (r != ncclSuccess) {
+            (void)R.GroupEnd();
+            return fail(RM_E_RCCL, "ncclAllGather failed: %s", R.GetErrorString(r));
+        }
+    }
+    RCCL_TRY(R.GroupEnd());
+    for (int k = 0; k < 3; ++k)
+        if ((rc = assemble(N, H, W, per, cyclic ? 1 : 0, eb[k], R.gather[k].p, dst[k], s))) return rc;
     return RM_OK;
 }
 

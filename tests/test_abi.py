@@ -17,7 +17,7 @@ def _header():
 
 
 def test_every_declared_symbol_is_exported():
-    declared = set(re.findall(r"^(?:int|void|size_t|const char\*)\s+(rm_\w+)\(", _header(), flags=re.M))
+    declared = set(re.findall(r"^(?:int|int32_t|void|size_t|const char\*)\s+(rm_\w+)\(", _header(), flags=re.M))
     assert declared and declared == set(_native.EXPORTS)
     lib = _native.load()
     for name in declared:
@@ -88,3 +88,30 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dp, f), encoding="utf-8", errors="replace").read()
                 for needle in ("import oracle", "from oracle", "oracle/", "oracle.render", "oracle.lib", "librm_oracle", "rmo_", "_build_host_check", "_build_math_check"):
                     assert needle not in text, (os.path.join(dp, f), needle)
+
+
+def test_shard_plan_in_c_equals_the_python_plan():
+    """rm_shard_rows / the row plan rm_gather_frame checks == sharding.plan_rows (a host-only call)."""
+    from raymarch_algo_compare_amd import sharding
+    lib = _native.load()
+    for H in (4, 37, 48, 50, 1080, 2160, 4320, 4321):
+        for N in (1, 2, 3, 4, 8):
+            per = lib.rm_shard_rows(H, N)
+            plans = [sharding.plan_rows(H, N, r) for r in range(N)]
+            if plans[0].cyclic:
+                assert H % (4 * N) == 0 and all(p.rows == H // N for p in plans)
+            elif N > 1:
+                assert [(p.row0, p.rows) for p in plans] == [(min(r * per, H), min((r + 1) * per, H) - min(r * per, H)) for r in range(N)]
+            assert sum(p.rows for p in plans) == H
+
+
+def test_rccl_entry_points_fail_loudly_without_a_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = _native.load()
+    ident = ctypes.create_string_buffer(128)
+    assert lib.rm_comm_init(ident, 1, 0) == -4            # RM_E_NO_DEVICE: rm_init has not succeeded
+    d = _native.make_desc(0, 0, [0.0] * 14, 8, 8)
+    assert lib.rm_gather_frame(ctypes.byref(d), None, None, None, None, None, None, None) == -4
+    assert lib.rm_comm_destroy() == 0                      # nothing to destroy
