@@ -284,6 +284,10 @@ int rm_get_pass_ms(void* stream, int32_t* npasses, float* ms);
 /* Single-launch frames: milliseconds after launch of the last push into and the last pop out of queue 1, as decoded
  * by the latest rm_get_pass_ms (0 when there was none).  A tuning aid: pop long after push = the teams fell behind. */
 int rm_last_queue_marks(float* last_push_ms, float* last_pop_ms);
+/* The same for the rays that ended with >= 500 iterations (the frame's longest chains): ms[0], ms[1] = earliest and
+ * latest time after launch at which one of them was handed to the teams, ms[2], ms[3] = shortest and longest time one
+ * of them then spent with a team. */
+int rm_long_ray_marks(float ms[4]);
 
 /* rm_render_batch with an outputs record: depth / iters / hit as above plus the optional frame-major evals map
  * (RmOutputs.evals; t_raw, final_sdf and block_var must be NULL).  With evals, stats[f].sum_evals is filled. */

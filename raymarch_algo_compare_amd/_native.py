@@ -26,7 +26,7 @@ EXPORTS = [
     "rm_default_strategy_params",
     "rm_sdf_eval", "rm_march_rays", "rm_march_rays_team", "rm_render", "rm_render_outputs", "rm_render_device", "rm_stats_device_bytes",
     "rm_read_stats", "rm_bench_device", "rm_alloc_frame", "rm_free_frame", "rm_copy_frame_to_host",
-    "rm_bench_store_path", "rm_render_batch", "rm_render_batch_outputs", "rm_set_pass_timing", "rm_get_pass_ms", "rm_last_queue_marks", "rm_set_queue_capacity",
+    "rm_bench_store_path", "rm_render_batch", "rm_render_batch_outputs", "rm_set_pass_timing", "rm_get_pass_ms", "rm_last_queue_marks", "rm_long_ray_marks", "rm_set_queue_capacity",
     "rm_comm_unique_id", "rm_comm_init", "rm_comm_destroy", "rm_shard_rows", "rm_gather_frame", "rm_assemble_frame",
 ]
 
@@ -178,6 +178,7 @@ def load() -> ctypes.CDLL:
         L.rm_set_queue_capacity.argtypes = [ctypes.c_int64]
         L.rm_get_pass_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_float)]
         L.rm_last_queue_marks.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+        L.rm_long_ray_marks.argtypes = [ctypes.POINTER(ctypes.c_float)]
         L.rm_comm_unique_id.argtypes = [ctypes.c_char_p]
         L.rm_comm_init.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32]
         L.rm_shard_rows.argtypes = [ctypes.c_int32, ctypes.c_int32]

@@ -99,6 +99,7 @@ struct State {
     int pass_count = 0;
     bool last_was_pipeline = false;                  // rm_get_pass_ms decodes the in-kernel marks of `last_stats`
     const unsigned long long* last_stats = nullptr;
+    float long_marks[4] = { 0.f, 0.f, 0.f, 0.f };    // longest rays: earliest / latest push, shortest / longest stay with a team
     float last_push_ms = 0.f, last_pop_ms = 0.f;     // queue-1 marks of the last single-launch frame decoded by rm_get_pass_ms
     uint32_t generation = 0;                         // tag of the queue entries of the latest single-launch frame
     hipEvent_t frame_ev = nullptr;                   // end of the latest frame, on `frame_stream` (frames share one workspace)
@@ -127,7 +128,7 @@ int check_desc(const RmFrameDesc* d)
         (!(d->band_rows > 0 && d->band_stride > 1) && d->row0 + d->rows > d->height))
         return fail(RM_E_BAD_DIMS, "bad frame slice: %dx%d rows [%d,%d)", d->width, d->height, d->row0, d->row0 + d->rows);
     if ((long long)d->width * d->height > (1ll << 31) - 1) return fail(RM_E_BAD_DIMS, "frame too large");
-    if (d->tile_rows != 0 && d->tile_rows != 4) return fail(RM_E_BAD_ARG, "tile_rows must be 0 or 4");
+    if (d->tile_rows != 0 && d->tile_rows != 4 && d->tile_rows != 1) return fail(RM_E_BAD_ARG, "tile_rows must be 0, 4 or 1");
     if (d->tile_order_mode < 0 || d->tile_order_mode > 2) return fail(RM_E_BAD_ARG, "tile_order_mode must be 0, 1 or 2");
     if (d->eval_mode < 0 || d->eval_mode > 2) return fail(RM_E_BAD_ARG, "eval_mode must be 0, 1 or 2");
     if (d->resume_mode < 0 || d->resume_mode > 3) return fail(RM_E_BAD_ARG, "resume_mode must be 0..3");
@@ -181,6 +182,7 @@ int make_args(const RmFrameDesc* d, float* depth, int32_t* iters, uint8_t* hit, 
     a->tiles_x = (d->width + rm::kTileW - 1) / rm::kTileW;
     a->tiles_y = (d->rows + th - 1) / th;
     a->tiles_per_frame = a->tiles_x * a->tiles_y;
+    a->tile_h = th;
     // refill batching: ray set-up (~250 instructions) is amortised over the idle lanes it serves; 8 idle lanes
     // measured best or equal on every scene (Pillar Forest 1.93 -> 1.69 ms against the 24 used earlier)
     a->refill_min = (d->refill_min > 0 && d->refill_min <= 64) ? d->refill_min : 8;
@@ -299,14 +301,13 @@ long long g_queue_cap = kQueueCapMax;           // rm_set_queue_capacity
 // 4-27 % faster than one launch per pass (1080p Standard 11.0-12.4 -> 9.9 ms, Enhanced 9.7 -> 7.9, Hybrid 6.2 ->
 // 5.0, 3840x2160 21.4 -> 15.7 ms); at 7680x4320 the frame is throughput-bound and wants every workgroup as a
 // producer (52.5 ms without suspension, 59 with the pipeline).  Other scenes keep their measured pass schedules.
-int pipeline_mode(const RmFrameDesc* d, int ntiles)
+int pipeline_mode(const RmFrameDesc* d, long long rays)
 {
     if (d->pipeline != 0) return d->pipeline;
-    const long long rays = (long long)ntiles * 256;
     return (d->scene_id == 10 && rays <= 24000000ll && d->march.max_iterations > 128) ? 2 : 1;
 }
 
-void suspend_levels(const RmFrameDesc* d, int ntiles, int mode, int* park)
+void suspend_levels(const RmFrameDesc* d, long long rays, int mode, int* park)
 {
     // Default: on for Mandelbulb launches of up to ~16 M rays -- those are bound by the latency of a few
     // hundred 512-trip rays (1080p: 15.2 -> 11.1 ms at 32 / 128 trips; 3840x2160: 22.8 -> 20.2 and
@@ -314,7 +315,6 @@ void suspend_levels(const RmFrameDesc* d, int ntiles, int mode, int* park)
     // without, 53-58 with), every other scene's SDF is too cheap for the extra passes to pay, and the
     // strategies whose rays end early or whose loop index restarts (Overstep-Bisect, Skipping-Spheres)
     // measured no faster or slower with it.
-    const long long rays = (long long)ntiles * 256;
     const bool strat_ok = d->strategy_id != 6 && d->strategy_id != 7;
     const bool dflt = d->scene_id == 10 && strat_ok && rays <= 16000000ll && d->march.max_iterations > 128;
     // Segment and RevAA evaluate the SDF twice per loop trip: half the trip budgets (Segment 19.7 -> 16.4 ms,
@@ -346,7 +346,8 @@ void suspend_levels(const RmFrameDesc* d, int ntiles, int mode, int* park)
     // to the teams at 48; larger frames, and Segment whose trips evaluate twice, at 32 / 64.  Every strategy gains,
     // Overstep-Bisect and Skipping-Spheres included (3.56 -> 3.08 ms, 11.3 -> 10.2 ms).
     if (mode == 2 && d->scene_id == 10 && d->march.max_iterations > 128) {
-        const bool small = rays <= 3000000ll && d->strategy_id != 10;
+        // (with the previous frame's tile costs the long rays start first and 32 / 64 measured best: 8.5 ms against 9.6)
+        const bool small = rays <= 3000000ll && d->strategy_id != 10 && d->tile_order_mode != 1;
         if (d->suspend_after[0] == 0) park[0] = small ? 16 : 32;
         if (d->suspend_after[1] == 0 && d->suspend_after[0] == 0) park[1] = small ? 48 : 64;
     }
@@ -384,6 +385,25 @@ int launch_frame(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, h
 {
     HIP_TRY(hipMemsetAsync(a.stats, 0, kStatsBytes, s));
     if (d->rows == 0) return RM_OK;
+    // launch structure and trip budgets first: the single launch of a scene with teams uses one-row tiles
+    const long long rays_total = (long long)a.rows * a.width * a.nframes;
+    int park[2];
+    const int mode = pipeline_mode(d, rays_total);
+    suspend_levels(d, rays_total, mode, park);
+    const rm::SceneLaunchers* const sc = rm::scene(d->scene_id);
+    if (d->tile_rows == 1 && !(park[0] > 0 && mode == 2 && sc->has_teams))
+        return fail(RM_E_BAD_ARG, "tile_rows = 1 exists for the single launch (pipeline = 2 with suspension) of scenes with a team form");
+    if (park[0] > 0 && mode == 2 && sc->has_teams && (d->tile_rows == 1 || (d->tile_rows == 0 && d->tile_order_mode == 1))) {
+        // 64x1 tiles: all 64 pixels of a tile start when the tile is opened.  With 64x4 tiles the last pixels of a
+        // tile wait in its pixel pool for lanes that rays of 16-48 trips hold (~1 ms each).  Default only with the
+        // previous frame's tile costs (tile_order_mode 1: the long rays' tiles are opened first, so their pixels
+        // should not queue inside them -- 1080p 9.6 -> 8.5 ms); with a static order 64x4 tiles measured better
+        // (9.9 against 10.9 ms: the tile order does not know where the long rays are).
+        tile_h = 1;
+        a.tile_h = 1;
+        a.tiles_y = a.rows;
+        a.tiles_per_frame = a.tiles_x * a.tiles_y;
+    }
     const int ntiles = a.tiles_per_frame * a.nframes;
     if (d->tile_order_mode == 1) {
         int rc;
@@ -411,9 +431,6 @@ int launch_frame(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, h
     }
     // long-ray suspension: pass 1 parks rays beyond suspend_after[0] trips, pass 2 restarts them all at
     // once and parks those beyond suspend_after[1], pass 3 finishes the few that remain
-    int park[2];
-    const int mode = pipeline_mode(d, ntiles);
-    suspend_levels(d, ntiles, mode, park);
     long long* const block_var = a.block_var;
     if (park[0] > 0) {
         const long long total = (long long)a.rows * a.width * a.nframes;
@@ -439,7 +456,6 @@ int launch_frame(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, h
     g.pass_count = 0;
     g.last_was_pipeline = false;
     if (pt) HIP_TRY(hipEventRecord(g.pev[0], s));
-    const rm::SceneLaunchers* const sc = rm::scene(d->scene_id);
     if (park[0] > 0 && mode == 2) {
         // ---- the whole frame in ONE launch (rm_pipeline.h): producers + queue-0 consumers + teams side by side
         const bool teams = sc->has_teams && park[1] > 0 && d->resume_mode != 1;
@@ -1236,6 +1252,10 @@ int rm_get_pass_ms(void* stream, int32_t* npasses, float* ms)
             // times of the last push into / pop out of queue 1 since launch, for tools (rm_last_queue_marks)
             g.last_push_ms = w[rm::kWMarkPush] >= start ? (float)((double)(w[rm::kWMarkPush] - start) * 1e-5) : 0.f;
             g.last_pop_ms = w[rm::kWMarkPop] >= start ? (float)((double)(w[rm::kWMarkPop] - start) * 1e-5) : 0.f;
+            g.long_marks[0] = w[rm::kWLongPushMin] ? (float)((double)(~w[rm::kWLongPushMin]) * 1e-5) : 0.f;
+            g.long_marks[1] = (float)((double)w[rm::kWLongPushMax] * 1e-5);
+            g.long_marks[2] = w[rm::kWLongTeamMin] ? (float)((double)(~w[rm::kWLongTeamMin]) * 1e-5) : 0.f;
+            g.long_marks[3] = (float)((double)w[rm::kWLongTeamMax] * 1e-5);
         }
     }
     return RM_OK;
@@ -1246,6 +1266,13 @@ int rm_last_queue_marks(float* last_push_ms, float* last_pop_ms)
     if (!last_push_ms || !last_pop_ms) return fail(RM_E_BAD_ARG, "NULL output");
     *last_push_ms = g.last_push_ms;
     *last_pop_ms = g.last_pop_ms;
+    return RM_OK;
+}
+
+int rm_long_ray_marks(float ms[4])
+{
+    if (!ms) return fail(RM_E_BAD_ARG, "NULL output");
+    for (int i = 0; i < 4; ++i) ms[i] = g.long_marks[i];
     return RM_OK;
 }
 

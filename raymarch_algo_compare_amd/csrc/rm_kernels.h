@@ -81,6 +81,7 @@ struct KernelArgs {
     int32_t full;                // all frames of a launch share cfg.full
     int32_t width, height, row0, rows;
     int32_t tiles_x, tiles_y;
+    int32_t tile_h;              // rows of a tile: 4 (64x4 pixels), or 1 in the single-launch pipeline of scenes with teams
     int32_t refill_min;
     int32_t interleave;          // scenes with a resumable SDF: one trip of the SDF loop per turn (see render_kernel)
     int32_t hist_bins;
@@ -956,7 +957,7 @@ struct SceneLaunchers {
     hipError_t (*render)(int strategy, int tile_h, const KernelArgs& a, int grid, hipStream_t s);
     hipError_t (*resume)(int strategy, int level, const KernelArgs& a, int grid, hipStream_t s);
     hipError_t (*resume_team)(int strategy, int level, const KernelArgs& a, int grid, hipStream_t s);   // nullptr: no team form
-    hipError_t (*pipeline)(int strategy, const KernelArgs& a, int grid, hipStream_t s);                  // rm_pipeline.h
+    hipError_t (*pipeline)(int strategy, const KernelArgs& a, int grid, hipStream_t s);                  // rm_pipeline.h (a.tile_h: 4, or 1 where has_teams)
     hipError_t (*occupancy_pipeline)(int strategy, int interleave, int batch, int* blocks_per_cu);
     bool has_teams;
     int (*entry_bytes)(int strategy);   // sizeof(QEntry<Strat>)

@@ -68,6 +68,7 @@ RM_MATH_HD double rm_acos_sqrt_band(double x, int m)          // 0.96875 <= |x| 
     return res + res;
 }
 
+template <bool U = false>
 RM_MATH_HD double rm_acos(double x)
 {
     typedef AtanK K;
@@ -78,46 +79,53 @@ RM_MATH_HD double rm_acos(double x)
     const double ax = rm_fabs(x);
 
     // |x| < 1/8: Taylor
-    const double x2 = x * x;
-    double pt = rm_fma(x2, K::f6, K::f5);
-    pt = rm_fma(x2, pt, K::f4);
-    pt = rm_fma(x2, pt, K::f3);
-    pt = rm_fma(x2, pt, K::f2);
-    pt = rm_fma(x2, pt, K::f1);
-    const double rt = K::hpi - x;
-    const double res_taylor = rt + rm_fnma(pt, x * x2, ((K::hpi - rt) - x) + K::hpi1);
+    double res_taylor = 0.0;
+    if (rm_band_needed<U>(k < 0x3fc00000)) {
+        const double x2 = x * x;
+        double pt = rm_fma(x2, K::f6, K::f5);
+        pt = rm_fma(x2, pt, K::f4);
+        pt = rm_fma(x2, pt, K::f3);
+        pt = rm_fma(x2, pt, K::f2);
+        pt = rm_fma(x2, pt, K::f1);
+        const double rt = K::hpi - x;
+        res_taylor = rt + rm_fnma(pt, x * x2, ((K::hpi - rt) - x) + K::hpi1);
+    }
 
     // 1/8 <= |x| < 0.96875: table band.  rm_asncs holds 216 uniform rows of 13 doubles (the generator
     // pads the shorter polynomials of e_asin.c's lower bands with zero leading coefficients):
     //   rows   0.. 31  |x| < 0.25 (step 2^-5 in the high word's bits 15..19), rows 32..95  |x| < 0.5,
     //   rows 96..215   0.5 <= |x| < 0.96875, index (k >> 13) & 0x7f
-    const int r1 = (k >> 15) & 0x1f, r2 = 32 + ((k >> 14) & 0x3f), r3 = 96 + ((k >> 13) & 0x7f);
-    int row = (k >= 0x3fd00000) ? r2 : r1;
-    row = (k >= 0x3fe00000) ? r3 : row;
-    row = (row > 215) ? 215 : row;                 // keeps the gather in bounds for out-of-band arguments
-    const double* a = rm_asncs + 13 * row;
-    const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5], a6 = a[6], a7 = a[7], a8 = a[8],
-                 a9 = a[9], a10 = a[10], c0 = a[11], cv = a[12];
-    const double xx = ax - a0;
-    double p = rm_fma(xx, a10, a9);                // degree-9 Horner; zero-padded coefficients leave the value unchanged
-    p = rm_fma(xx, p, a8);
-    p = rm_fma(xx, p, a7);
-    p = rm_fma(xx, p, a6);
-    p = rm_fma(xx, p, a5);
-    p = rm_fma(xx, p, a4);
-    p = rm_fma(xx, p, a3);
-    p = rm_fma(xx, p, a2);
-    p = rm_fma(xx * xx, p, c0);
-    const double t = rm_fma(xx, a1, p);
-    const double yb = pos ? (K::hpi - cv) : (cv + K::hpi);
-    const double tb = pos ? (K::hpi1 - t) : (t + K::hpi1);
-    const double res_band = tb + yb;
+    double res_band = 0.0;
+    if (rm_band_needed<U>(k >= 0x3fc00000 && k < 0x3fef0000)) {
+        const int r1 = (k >> 15) & 0x1f, r2 = 32 + ((k >> 14) & 0x3f), r3 = 96 + ((k >> 13) & 0x7f);
+        int row = (k >= 0x3fd00000) ? r2 : r1;
+        row = (k >= 0x3fe00000) ? r3 : row;
+        row = (row > 215) ? 215 : row;                 // keeps the gather in bounds for out-of-band arguments
+        const double* a = rm_asncs + 13 * row;
+        const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5], a6 = a[6], a7 = a[7], a8 = a[8],
+                     a9 = a[9], a10 = a[10], c0 = a[11], cv = a[12];
+        const double xx = ax - a0;
+        double p = rm_fma(xx, a10, a9);                // degree-9 Horner; zero-padded coefficients leave the value unchanged
+        p = rm_fma(xx, p, a8);
+        p = rm_fma(xx, p, a7);
+        p = rm_fma(xx, p, a6);
+        p = rm_fma(xx, p, a5);
+        p = rm_fma(xx, p, a4);
+        p = rm_fma(xx, p, a3);
+        p = rm_fma(xx, p, a2);
+        p = rm_fma(xx * xx, p, c0);
+        const double t = rm_fma(xx, a1, p);
+        const double yb = pos ? (K::hpi - cv) : (cv + K::hpi);
+        const double tb = pos ? (K::hpi1 - t) : (t + K::hpi1);
+        res_band = tb + yb;
+    }
 
     double res = (k < 0x3fc00000) ? res_taylor : res_band;
     res = (k < 0x3c880000) ? K::hpi : res;                        // |x| < 2^-55
-    // |x| >= 0.96875: 1/sqrt band, |x| == 1, invalid -- evaluated unconditionally and selected, so
+    // |x| >= 0.96875: 1/sqrt band, |x| == 1, invalid -- without U evaluated unconditionally and selected, so
     // the routine is one straight-line block (the z argument is clamped to stay in the table)
-    const double res_sqrt = rm_acos_sqrt_band(x, m);
+    double res_sqrt = 0.0;
+    if (rm_band_needed<U>(k >= 0x3fef0000 && k < 0x3ff00000)) res_sqrt = rm_acos_sqrt_band(x, m);
     res = (k >= 0x3fef0000) ? res_sqrt : res;
     const double at_one = pos ? 0.0 : K::opi;                                    // |x| == 1
     const bool is_one = (k == 0x3ff00000) & ((uint32_t)bits == 0);
@@ -144,6 +152,7 @@ RM_MATH_HD double rm_atan_series(double v)   // d3 + v*(d5 + v*(d7 + v*(d9 + v*(
     return rm_fma(v, p, K::d3);
 }
 
+template <bool U = false>
 RM_MATH_HD double rm_atan2(double y, double x)
 {
     typedef AtanK K;
@@ -169,41 +178,51 @@ RM_MATH_HD double rm_atan2(double y, double x)
     const bool plus = !xpos & (ax < ay);
     const double B = case_iv ? K::opi : K::hpi, B1 = case_iv ? K::opi1 : K::hpi1;
 
+    const bool small = u < 0.0625;
     // series forms (u < 1/16)
-    const double v2 = u * u;
-    const double ser = rm_atan_series(v2);
-    const double uv = u * v2;
-    const double z_is = u + rm_fma(uv, ser, du);
-    const double su = plus ? u : -u, sdu = plus ? du : -du;
-    const double zz_s = uv * ser;
-    const double t2 = B + su;
-    const double cor = (B - t2) + su;
-    const double z_os = (((cor + B1) + sdu) + (plus ? zz_s : -zz_s)) + t2;
+    double z_is = 0.0, z_os = 0.0;
+    if (rm_band_needed<U>(small)) {
+        const double v2 = u * u;
+        const double ser = rm_atan_series(v2);
+        const double uv = u * v2;
+        z_is = u + rm_fma(uv, ser, du);
+        const double su = plus ? u : -u, sdu = plus ? du : -du;
+        const double zz_s = uv * ser;
+        const double t2 = B + su;
+        const double cor = (B - t2) + su;
+        z_os = (((cor + B1) + sdu) + (plus ? zz_s : -zz_s)) + t2;
+    }
 
     // table forms
-    int i = (int)(rm_fma(u, 256.0, 0x1p52) - 0x1p52) - 16;
-    i = (i < 0) ? 0 : ((i > 240) ? 240 : i);      // in range whenever the table form is selected
-    const double* c = rm_cij + 7 * i;
-    const double c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5], c6 = c[6];
-    const double t3 = u - c0;
-    // (i): EADD(t3, du, v, dv), zz = v*c2 + (dv*c2 + v*v*(c3 + v*(c4 + v*(c5 + v*c6))))
-    const double vi = du + t3;
-    const double dv = (rm_fabs(t3) > rm_fabs(du)) ? ((t3 - vi) + du) : ((du - vi) + t3);
-    double pi_ = rm_fma(vi, c6, c5);
-    pi_ = rm_fma(vi, pi_, c4);
-    pi_ = rm_fma(vi, pi_, c3);
-    pi_ = (vi * vi) * pi_;
-    pi_ = rm_fma(dv, c2, pi_);
-    const double z_it = rm_fma(vi, c2, pi_) + c1;
-    // (ii)-(iv): v = (u - c0) + du, zz = B1 -+ v*(c2 + v*(c3 + v*(c4 + v*(c5 + v*c6)))), z = (B -+ c1) + zz
-    const double vo = t3 + du;
-    double po = rm_fma(vo, c6, c5);
-    po = rm_fma(vo, po, c4);
-    po = rm_fma(vo, po, c3);
-    po = rm_fma(vo, po, c2);
-    const double z_ot = (B + (plus ? c1 : -c1)) + rm_fma(plus ? vo : -vo, po, B1);
+    double z_it = 0.0, z_ot = 0.0;
+    if (rm_band_needed<U>(!small)) {
+        int i = (int)(rm_fma(u, 256.0, 0x1p52) - 0x1p52) - 16;
+        i = (i < 0) ? 0 : ((i > 240) ? 240 : i);      // in range whenever the table form is selected
+        const double* c = rm_cij + 7 * i;
+        const double c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5], c6 = c[6];
+        const double t3 = u - c0;
+        // (i): EADD(t3, du, v, dv), zz = v*c2 + (dv*c2 + v*v*(c3 + v*(c4 + v*(c5 + v*c6))))
+        if (rm_band_needed<U>(!small & case_i)) {
+            const double vi = du + t3;
+            const double dv = (rm_fabs(t3) > rm_fabs(du)) ? ((t3 - vi) + du) : ((du - vi) + t3);
+            double pi_ = rm_fma(vi, c6, c5);
+            pi_ = rm_fma(vi, pi_, c4);
+            pi_ = rm_fma(vi, pi_, c3);
+            pi_ = (vi * vi) * pi_;
+            pi_ = rm_fma(dv, c2, pi_);
+            z_it = rm_fma(vi, c2, pi_) + c1;
+        }
+        // (ii)-(iv): v = (u - c0) + du, zz = B1 -+ v*(c2 + v*(c3 + v*(c4 + v*(c5 + v*c6)))), z = (B -+ c1) + zz
+        if (rm_band_needed<U>(!small & !case_i)) {
+            const double vo = t3 + du;
+            double po = rm_fma(vo, c6, c5);
+            po = rm_fma(vo, po, c4);
+            po = rm_fma(vo, po, c3);
+            po = rm_fma(vo, po, c2);
+            z_ot = (B + (plus ? c1 : -c1)) + rm_fma(plus ? vo : -vo, po, B1);
+        }
+    }
 
-    const bool small = u < 0.0625;
     const double z_i = small ? z_is : z_it, z_o = small ? z_os : z_ot;
     double z = case_i ? z_i : z_o;
     // special operands (e_atan2.c:66-133), resolved by selects in the reference's priority order

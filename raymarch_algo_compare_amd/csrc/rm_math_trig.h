@@ -37,6 +37,22 @@ struct SinCosK {
 
 RM_MATH_HD double rm_fnma(double a, double b, double c) { return rm_fma(-a, b, c); }   // -(a*b) + c, one rounding
 
+// Wave-uniform band skipping (template flag U of rm_acos / rm_atan2 / rm_sincos).  The routines evaluate every
+// band and select, which is what a full wavefront of unrelated lanes wants (no divergence).  A wavefront TEAM
+// (rm_kernels.h) is the opposite case: one wave alone on its SIMD, a handful of live lanes, and every fp64
+// instruction it issues costs 8 cycles of the frame's critical chain whether its result is selected or not.
+// With U a band is evaluated only if some live lane of the wave selects it (one ballot per band); the selected
+// value is computed by the same instructions either way, so results are bit-identical.
+template <bool U>
+RM_MATH_HD bool rm_band_needed(bool lane_selects)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (U) return __any(lane_selects) != 0;
+#endif
+    (void)lane_selects;
+    return true;
+}
+
 // TAYLOR_SIN(xx, x, dx): x + ((POLYNOMIAL(xx)*x - 0.5*dx)*xx + dx)
 RM_MATH_HD double rm_taylor_sin(double x, double dx)
 {
@@ -60,11 +76,13 @@ RM_MATH_HD int rm_sincos_row(double u)
 }
 
 // do_sin(x, dx), branch-free: Taylor below 0.126, table otherwise (both evaluated, one selected)
+template <bool U = false>
 RM_MATH_HD double rm_do_sin(double a, double da)
 {
     typedef SinCosK K;
     const double aa = rm_fabs(a);
-    const double taylor = rm_taylor_sin(a, da);          // uses dx before the sign flip, as s_sin.c does
+    double taylor = 0.0;
+    if (rm_band_needed<U>(aa < 0.126)) taylor = rm_taylor_sin(a, da);   // uses dx before the sign flip, as s_sin.c does
     const double dx = (a <= 0.0) ? -da : da;
     const double u = K::big + aa;
     const double x = aa - (u - K::big);
@@ -100,6 +118,7 @@ RM_MATH_HD double rm_do_cos(double a, double da)
 //   |x| < 2.426265          sin = copysign(do_cos(hp0-|x|, hp1), x)    cos = do_sin(a, da), a = y+hp1, da = (y-a)+hp1
 //   |x| < 105414350         reduce_sincos -> (a, da, n): sin = do_sincos(a, da, n), cos = do_sincos(a, da, n+1)
 // so the two kernels are evaluated once each on selected inputs and the outputs are routed by selects.
+template <bool U = false>
 RM_MATH_HD void rm_sincos(double x, double* sin_out, double* cos_out)
 {
     typedef SinCosK K;
@@ -124,7 +143,7 @@ RM_MATH_HD void rm_sincos(double x, double* sin_out, double* cos_out)
 
     // single-level selects only (a nested ?: comes back from the compiler as a branch)
     const double aS = r2 ? a2 : b, daS = r2 ? da2 : db, aC = r2 ? tt : b, daC = r2 ? K::hp1 : db;
-    const double dS = rm_do_sin(aS, daS);
+    const double dS = rm_do_sin<U>(aS, daS);
     const double dC = rm_do_cos(aC, daC);
 
     // range 3 (and 1, n = 0) routing: do_sincos(a, da, n) = (n & 1 ? do_cos : do_sin), negated when n & 2

@@ -61,6 +61,12 @@ constexpr int kWMarkProd = 15;    // max s_memrealtime when a producer wave exit
 constexpr int kWMarkTiles = 17;   // ~min s_memrealtime when a wave found the tile counter exhausted
 constexpr int kWMarkPush = 18;    // max s_memrealtime of a push into queue 1
 constexpr int kWMarkPop = 19;     // max s_memrealtime of a pop out of queue 1
+// tuning marks of the frame's longest rays (those that end with >= kLongRay iterations), 100 MHz ticks:
+constexpr int kWLongPushMax = 20; // latest time since launch at which one of them entered queue 1
+constexpr int kWLongTeamMax = 21; // longest time one of them spent between that push and its end
+constexpr int kWLongTeamMin = 22; // ~shortest such time
+constexpr int kWLongPushMin = 23; // ~earliest push
+constexpr int kLongRay = 500;
 constexpr int kWError = 16;       // != 0: a wait of the queue protocol ran into its bound (the host reports RM_E_HIP)
 // No wait in this kernel is unbounded: a protocol bug or a lost workgroup must end in an error code, never in a
 // hung device.  Bounds are far beyond anything a healthy launch reaches.
@@ -151,7 +157,7 @@ __device__ __forceinline__ bool q_push(const KernelArgs& a, int q, bool want, ui
         e.gi = gi;
         e.nev = (uint32_t)nev;
         e.ready = 0u;
-        e.pad = 0u;
+        e.pad = (uint32_t)(realtime() - ~ld_relaxed(&a.stats[kWMarkStart]));      // push time since launch (tuning marks)
         e.s = s;
         unsigned long long w[NW];
         __builtin_memcpy(w, &e, sizeof e);
@@ -159,6 +165,7 @@ __device__ __forceinline__ bool q_push(const KernelArgs& a, int q, bool want, ui
 #pragma unroll
         for (int k = 0; k < NW; ++k)
             if (k != 1) __hip_atomic_store(dst + k, w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((uint32_t*)(dst + 1) + 1, e.pad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // upper half of word 1
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing lane's entry has left the wave
     if (ok) __hip_atomic_store((uint32_t*)(dst + 1), a.generation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -267,7 +274,7 @@ __device__ __forceinline__ void store_direct(const KernelArgs& a, uint32_t gi, c
         const uint32_t frame = gi / frame_elems;
         const uint32_t pix = gi - frame * frame_elems;
         const uint32_t y = pix / (uint32_t)a.width, x = pix - y * (uint32_t)a.width;
-        atomicMax(&a.tile_cost[frame * (uint32_t)a.tiles_per_frame + (y / 4u) * (uint32_t)a.tiles_x + (x >> 6)], it);
+        atomicMax(&a.tile_cost[frame * (uint32_t)a.tiles_per_frame + (y / (uint32_t)a.tile_h) * (uint32_t)a.tiles_x + (x >> 6)], it);
     }
 }
 
@@ -324,6 +331,7 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
         unsigned int epoch = 0;               // this team's barrier count (identical in its three waves)
         bool active = false;
         uint32_t my_gi = 0;
+        uint32_t my_push = 0;                 // when this ray entered the queue (ticks since launch; tuning marks)
         int nev = 0;
         vec3 origin = v3(0.0, 0.0, 0.0), dir = v3(0.0, 0.0, 0.0);
         MarchCfg lane_cfg = a.single.cfg;
@@ -374,6 +382,7 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
                         my_gi = e->gi;
                         nev = (int)e->nev;
                         s = e->s;
+                        my_push = e->pad;
                         uint32_t frame; int x, gy;
                         element_pixel(a, my_gi, frame, x, gy);
                         if constexpr (BATCH) {
@@ -408,7 +417,16 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
                 ++nev;
                 if (s.step(Scene::value(ev), cfg)) {
                     active = false;
-                    if (part == 0) store_direct(a, my_gi, s.res, nev, acc, L.hist);
+                    if (part == 0) {
+                        store_direct(a, my_gi, s.res, nev, acc, L.hist);
+                        if (s.res.iters >= kLongRay) {        // tuning marks of the frame's longest rays
+                            const unsigned long long now = realtime() - ~ld_relaxed(&a.stats[kWMarkStart]);
+                            atomicMax(&a.stats[kWLongPushMax], (unsigned long long)my_push);
+                            atomicMax(&a.stats[kWLongPushMin], ~(unsigned long long)my_push);
+                            atomicMax(&a.stats[kWLongTeamMax], now - my_push);
+                            atomicMax(&a.stats[kWLongTeamMin], ~(now - my_push));
+                        }
+                    }
                 }
             }
         }
@@ -608,9 +626,15 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
                 bool started = false;
                 if (!active) {
                     const int id = pool_next + rank_in_mask(idle);
-                    const int blk = id >> 5, within = id & 31;
-                    const int px = (blk & 7) * 8 + (within & 7);
-                    const int py = (blk >> 3) * 4 + (within >> 3);
+                    int px, py;
+                    if constexpr (TILE_H == 4) {          // block-major: 32 consecutive ids form one 8x4 block
+                        const int blk = id >> 5, within = id & 31;
+                        px = (blk & 7) * 8 + (within & 7);
+                        py = (blk >> 3) * 4 + (within >> 3);
+                    } else {                              // one-row tiles: the 64 pixels of the tile start together
+                        px = id & (kTileW - 1);
+                        py = id >> 6;
+                    }
                     if (id < TILE_PIX && px < cg.tw && py < cg.th) {
                         my_slot = cur;
                         my_pix = py * kTileW + px;

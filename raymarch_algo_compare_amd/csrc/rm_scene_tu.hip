@@ -58,19 +58,31 @@ static hipError_t occ_render(int interleave, int batch, int* blocks)
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, render_kernel<SceneT, Strat, TH, false, false>, 64 * kWavesPerWG, 0);
 }
 
-template <class Strat>
-static hipError_t launch_pipeline(const KernelArgs& a, int grid, hipStream_t s)
+// One-row tiles (TILE_H = 1) are built for the scenes with a team form only: there a frame ends with its longest
+// ray, and with 64x4 tiles that ray may sit in its tile's pixel pool for milliseconds behind lanes that older rays hold.
+template <class Strat, int TH>
+static hipError_t launch_pipeline_th(const KernelArgs& a, int grid, hipStream_t s)
 {
     const bool il = kIter && a.interleave;
     const dim3 g(grid), b(64 * kPipeWaves);
     if (a.frames) {
-        if (il) hipLaunchKernelGGL((pipeline_kernel<SceneT, Strat, 4, kIter, true>), g, b, 0, s, a);
-        else hipLaunchKernelGGL((pipeline_kernel<SceneT, Strat, 4, false, true>), g, b, 0, s, a);
+        if (il) hipLaunchKernelGGL((pipeline_kernel<SceneT, Strat, TH, kIter, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((pipeline_kernel<SceneT, Strat, TH, false, true>), g, b, 0, s, a);
     } else {
-        if (il) hipLaunchKernelGGL((pipeline_kernel<SceneT, Strat, 4, kIter, false>), g, b, 0, s, a);
-        else hipLaunchKernelGGL((pipeline_kernel<SceneT, Strat, 4, false, false>), g, b, 0, s, a);
+        if (il) hipLaunchKernelGGL((pipeline_kernel<SceneT, Strat, TH, kIter, false>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((pipeline_kernel<SceneT, Strat, TH, false, false>), g, b, 0, s, a);
     }
     return hipGetLastError();
+}
+
+template <class Strat>
+static hipError_t launch_pipeline(const KernelArgs& a, int grid, hipStream_t s)
+{
+    if constexpr (kIter) {
+        if (a.tile_h == 1) return launch_pipeline_th<Strat, 1>(a, grid, s);
+    }
+    if (a.tile_h != 4) return hipErrorInvalidValue;
+    return launch_pipeline_th<Strat, 4>(a, grid, s);
 }
 
 template <class Strat>

@@ -191,17 +191,19 @@ struct SceneMandelbulb {                                                        
     //   part 2:  r ** 7.0 and r ** 8.0                                        (:280, :283)
     // trip_part evaluates one of them, trip_join does the rest of the trip from all six values.
     // trip(e) == trip_join(e, parts 0..2): same expressions, same order, same bits.
+    // (wave-uniform band skipping inside acos / atan2 / sincos: a team wave is alone on its SIMD with few live
+    // lanes, every instruction it does not issue shortens the frame's critical chain -- rm_math_trig.h)
     static RM_HD void trip_part(const Eval& e, int part, double& o0, double& o1)
     {
         const double power = 8.0;
         if (part == 0) {
-            double theta = rm_acos(py_max(-1.0, py_min(1.0, e.z.z / py_max(e.r, 1e-12))));
+            double theta = rm_acos<true>(py_max(-1.0, py_min(1.0, e.z.z / py_max(e.r, 1e-12))));
             theta *= power;
-            rm_sincos(theta, &o0, &o1);
+            rm_sincos<true>(theta, &o0, &o1);
         } else if (part == 1) {
-            double phi = rm_atan2(e.z.y, e.z.x);
+            double phi = rm_atan2<true>(e.z.y, e.z.x);
             phi *= power;
-            rm_sincos(phi, &o0, &o1);
+            rm_sincos<true>(phi, &o0, &o1);
         } else {
             rm_pow2(e.r, power - 1.0, power, &o0, &o1);
         }

@@ -22,10 +22,12 @@ def run(sid=10, kid=0, W=1920, H=1080, repeats=7, warmup=2, **tuning):
     _native.check(L.rm_set_pass_timing(0))
     lp, lq = ctypes.c_float(0), ctypes.c_float(0)
     _native.check(L.rm_last_queue_marks(ctypes.byref(lp), ctypes.byref(lq)))
+    lm = (ctypes.c_float * 4)()
+    _native.check(L.rm_long_ray_marks(lm))
     st = out["stats"]
     r = dict(ms=round(out["timing"]["ms_median"], 3), ms_min=round(out["timing"]["ms_min"], 3),
              mrays=round(W * H / out["timing"]["ms_median"] / 1e3, 1), passes=[round(ms[i], 3) for i in range(n.value)],
-             q1_last_push_pop=[round(lp.value, 2), round(lq.value, 2)], **{k: v for k, v in tuning.items()})
+             q1_last_push_pop=[round(lp.value, 2), round(lq.value, 2)], long_push_min_max_team_min_max=[round(lm[i], 2) for i in range(4)], **{k: v for k, v in tuning.items()})
     if (W, H) != (1920, 1080): r["WxH"] = f"{W}x{H}"
     if (sid, kid) != (10, 0): r["cell"] = f"{scene.name}/{registry.list_strategies()[kid]}"
     print(json.dumps(r), flush=True)
@@ -41,6 +43,26 @@ if exp == "q0":
                 run(pipeline=2, suspend_after=b, queue_first=qf, team_grid=tg)
     for kw in (dict(queue_refill_min=4), dict(queue_refill_min=32), dict(team_steal=2), dict(queue_retry=4), dict(queue_retry=64)):
         run(pipeline=2, suspend_after=(16, 48), queue_first=1, **kw)
+elif exp == "retry":
+    for tr in (2, 4, 8, 16, 32, 64):
+        run(pipeline=2, team_retry=tr)
+        run(pipeline=2, team_retry=tr, tile_order_mode=1)
+    for tg in (160, 192):
+        for tr in (8, 16, 32):
+            run(pipeline=2, team_retry=tr, team_grid=tg)
+elif exp == "long":
+    for tr in (4, 0):
+        for tom in (0, 1):
+            for b in ((16, 48), (32, 64)):
+                run(pipeline=2, suspend_after=b, tile_rows=tr, tile_order_mode=tom)
+elif exp == "th1":
+    for tr in (4, 0):
+        for b in ((16, 48), (32, 48), (32, 64), (24, 40)):
+            for tg in (96, 128, 160):
+                run(pipeline=2, suspend_after=b, team_grid=tg, tile_rows=tr)
+    run(pipeline=2, tile_order_mode=1)
+    run(pipeline=2, tile_order_mode=1, suspend_after=(32, 48))
+    run(pipeline=2, tile_order_mode=2)
 elif exp == "marks":
     for tg in (64, 128, 192):
         for b in ((16, 48), (32, 64), (32, 96), (32, 128)):
