@@ -90,7 +90,8 @@ typedef struct RmFrameDesc {
     int32_t row0, rows;
     double cam[14];
     RmMarchConfig march;
-    int32_t tile_rows;   /* 0 = default; rows per 64-pixel-wide wave tile (only 4 is built) */
+    int32_t tile_rows;   /* 0 = default; rows per 64-pixel-wide wave tile: 4, or 1 for the single launch (pipeline = 2 with
+                          * suspension) of scenes with a team form -- default there when tile_order_mode = 1 */
     int32_t refill_min;  /* 0 = default; idle lanes required before a wave refills */
     int32_t grid_waves;  /* 0 = default (fill the device); persistent wavefront count */
     /* Band-cyclic row sharding (multi-GPU load balance): local row y of this slice is image row

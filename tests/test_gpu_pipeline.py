@@ -134,3 +134,53 @@ def test_pass_marks_of_a_single_launch(hip):
         assert n.value == 4 and all(ms[i] >= 0.0 for i in range(4)) and sum(ms) > 0.0
     finally:
         hip.check(L.rm_set_pass_timing(0))
+
+
+def test_frames_in_flight_on_two_streams_do_not_share_state(hip):
+    """The parked-ray queues, control block and tile-cost maps are one workspace per device: frames enqueued from
+    two host threads on two HIP streams must come out as if rendered alone (the library orders them with an event).
+    Streams come from the HIP runtime directly -- the boundary takes a plain hipStream_t."""
+    import ctypes
+    import threading
+    L = hip.load()
+    rt = ctypes.CDLL("libamdhip64.so")
+    rt.hipStreamCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+    rt.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    rt.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+    G = golden_frames("160x120")
+    cells = [(10, 0, dict(pipeline=2, suspend_after=(6, 30))), (10, 4, dict(pipeline=0, suspend_after=(5, 25))),
+             (14, 0, dict(pipeline=2, suspend_after=(4, 12))), (10, 7, dict(pipeline=2, suspend_after=(3, 9), tile_order_mode=1))]
+    vp = ctypes.c_void_p
+    results, errors = {}, []
+
+    def worker(tid):
+        try:
+            stream = vp()
+            assert rt.hipStreamCreate(ctypes.byref(stream)) == 0
+            for rep in range(6):
+                sid, kid, sched = cells[(tid * 2 + rep) % len(cells)]
+                g = G.get(sid, kid)
+                w, h = g["W"], g["H"]
+                desc = hip.make_desc(sid, kid, g["cam"], w, h, 0, h, g["max_iterations"], g["hit_threshold"],
+                                     g["max_distance"], g["lipschitz"], False, **sched)
+                p = [vp(), vp(), vp()]
+                hip.check(L.rm_alloc_frame(w, h, *[ctypes.byref(q) for q in p]))
+                hip.check(L.rm_render_device(ctypes.byref(desc), p[0], p[1], p[2], None, stream))
+                assert rt.hipStreamSynchronize(stream) == 0
+                depth, iters, hit = np.empty((h, w), np.float32), np.empty((h, w), np.int32), np.empty((h, w), np.uint8)
+                hip.check(L.rm_copy_frame_to_host(w, h, p[0], p[1], p[2], depth.ctypes.data_as(vp), iters.ctypes.data_as(vp),
+                                                  hit.ctypes.data_as(vp)))
+                hip.check(L.rm_free_frame(*p))
+                results[(tid, rep)] = (sid, kid, (iters == g["iters"]).all() and (hit.astype(bool) == g["hit"].astype(bool)).all()
+                                       and float(np.abs(depth - g["depth"]).max()) <= 1e-5)
+            rt.hipStreamDestroy(stream)
+        except Exception as e:                                   # noqa: BLE001 -- reported by the main thread
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert len(results) == 12 and all(ok for _, _, ok in results.values()), results

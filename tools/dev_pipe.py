@@ -35,7 +35,23 @@ def run(sid=10, kid=0, W=1920, H=1080, repeats=7, warmup=2, **tuning):
 
 
 exp = sys.argv[1] if len(sys.argv) > 1 else "first"
-if exp == "q0":
+if exp == "misc":
+    # host-buffer boundary (PCIe copy back included), a band-cyclic 1/8 shard of the 8K frame, the unsharded 8K frame
+    import time
+    scene = registry.SCENES[10]
+    _native.init()
+    desc = _native.make_desc(10, 0, cam_for(scene, 1920, 1080).params14(), 1920, 1080)
+    _native.render(desc)
+    ts = []
+    for _ in range(9):
+        t0 = time.perf_counter(); _native.render(desc); ts.append((time.perf_counter() - t0) * 1e3)
+    print(json.dumps({"rm_render_host_wall_ms": sorted(round(t, 2) for t in ts)}), flush=True)
+    run(W=7680, H=4320, rows=540, band_rows=4, band_stride=8, band_offset=0)
+    run(W=7680, H=4320, rows=540, band_rows=4, band_stride=8, band_offset=5)
+    run(W=7680, H=4320, rows=1080, band_rows=4, band_stride=4, band_offset=1)
+    run(W=7680, H=4320, rows=2160, band_rows=4, band_stride=2, band_offset=1)
+    run(W=7680, H=4320)
+elif exp == "q0":
     run(pipeline=2)
     for qf in (1, 2):
         for b in ((16, 48), (32, 64), (24, 48), (32, 96), (16, 32)):
