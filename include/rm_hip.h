@@ -101,11 +101,15 @@ typedef struct RmFrameDesc {
     int32_t band_rows;
     int32_t band_stride;
     int32_t band_offset;
-    /* Tile scheduling order.  0: natural (row-major tiles).  1: longest-first using the per-tile cost
-     * (max iterations) the previous render of the SAME frame shape left in the library workspace --
-     * rays that ran long last frame start first, so they no longer finish last (results are
-     * identical in either mode; only the schedule changes).  Falls back to 0 when no matching
-     * previous frame exists. */
+    /* Tile scheduling order (results are identical in every mode; only the schedule changes -- a frame ends with its
+     * longest ray, and that ray starts when the order reaches its tile).
+     *   0  the library's choice: centre-out for one-frame launches of every scene but those measured better in natural
+     *      order (Pillar Forest), natural for batches of cheap scenes
+     *   1  longest-first using the per-tile cost (max iterations) the previous render of the SAME frame shape left in the
+     *      library workspace -- rays that ran long last frame start first; natural order when no matching previous frame exists
+     *   2  centre-out: a static permutation of the frame shape, cached until the shape changes (the registry's cameras
+     *      look at their object, so the object's grazing / fractal rays start first)
+     *   3  natural (row-major tiles) */
     int32_t tile_order_mode;
     /* Scenes whose SDF is a data-dependent loop (Mandelbulb, catalog.py:266-293).  0 = default
      * (library's choice, currently 2); 1 = a whole SDF evaluation per wave turn; 2 = one trip of the
@@ -139,9 +143,9 @@ typedef struct RmFrameDesc {
      *   queue_refill_min idle lanes a producer wave needs before it looks at queue 0
      *   queue_retry      turns between two looks of a producer wave whose lanes stay idle
      *   team_retry       evaluations between two looks of a team that still carries rays
-     *   age_priority     (every launch structure) > 0: a wave raises its issue priority (s_setprio) to
-     *                    (trips of its oldest ray) / age_priority, capped at 3, so the waves that carry the frame's
-     *                    longest chains win the SIMD they share with waves of short rays; results unchanged */
+     *   age_priority     accepted and ignored by this build (an experiment: waves raising their issue priority with the
+     *                    trip count of their oldest ray measured no gain on any scene and cost the cheap scenes 6-8 %;
+     *                    rm::kAgePriority in csrc/rm_kernels.h builds it) */
     int32_t pipeline;
     int32_t team_grid;
     int32_t queue_first;

@@ -57,7 +57,16 @@ RM_HD vec3 operator-(vec3 a, vec3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z
 RM_HD vec3 operator*(vec3 a, double s) { return v3(a.x * s, a.y * s, a.z * s); }       // vec3.py:23-24
 RM_HD double dot(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }         // vec3.py:36-37
 // vec3.py:46-47: (x*x + y*y + z*z) ** 0.5 -- float_pow, i.e. libm pow(s, 0.5)
-RM_HD double length(vec3 a) { return rm_pow(a.x * a.x + a.y * a.y + a.z * a.z, 0.5); }
+RM_HD double pow_half(double x) { return rm_pow(x, 0.5); }
+RM_HD double length(vec3 a) { return pow_half(a.x * a.x + a.y * a.y + a.z * a.z); }
+// The same values for call sites on a frame's critical chain: the full pow in a busy wavefront, the guarded square
+// root in a nearly empty one (rm_math_pow.h: rm_pow_half) -- same bits either way.  Only where it measured faster
+// (MI355X, 1920x1080): Mandelbulb (single launch 10.1 -> 9.6 ms: every wave of a team repeats the trip's length), the
+// two torus primitives (Thin Torus -4 %, Capped Torus -6 %).  Elsewhere the wave-uniform branch it brings costs more
+// than the sparse tail saves: it separates the independent pow chains of multi-primitive scenes (Sphere Cloud and
+// Bumpy Sphere +34 %, Pillar Forest +7 %, Menger +4 %).
+RM_HD double pow_half_a(double x) { return rm_pow_half<true>(x); }
+RM_HD double length_a(vec3 a) { return pow_half_a(a.x * a.x + a.y * a.y + a.z * a.z); }
 RM_HD vec3 normalized(vec3 a)                                                          // vec3.py:52-56
 {
     double l = length(a);

@@ -73,6 +73,36 @@ struct FrameParams {
     MarchCfg cfg;
 };
 
+// One-frame launches: the march configuration is wave-uniform (kernel arguments).  Left to itself the compiler
+// re-reads the fields a strategy consults from the kernarg segment INSIDE the march loop -- scalar registers are
+// short in these kernels -- i.e. s_load + s_waitcnt on every turn: measured +6 % (Cube), +10 % (Sphere), +4.7 %
+// (Mandelbulb 7680x4320) against per-lane copies.  Passing a field through an empty asm with a VGPR constraint
+// makes it an ordinary per-lane value that stays in vector registers for the life of the wave; fields the
+// strategy never reads disappear together with their asm.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RM_PIN_LANE(x) asm("" : "+v"(x))
+#else
+#define RM_PIN_LANE(x) (void)(x)      // host pass of the translation unit
+#endif
+__device__ __forceinline__ void pin_lane(double& x) { RM_PIN_LANE(x); }
+__device__ __forceinline__ void pin_lane(int32_t& x) { RM_PIN_LANE(x); }
+template <class T> __device__ __forceinline__ void pin_lane(T*& x) { RM_PIN_LANE(x); }
+__device__ __forceinline__ void pin_cfg(MarchCfg& c)
+{
+    pin_lane(c.hit_threshold); pin_lane(c.max_distance); pin_lane(c.lipschitz); pin_lane(c.max_iterations);
+    StratParams& p = c.prm;
+    pin_lane(p.omega); pin_lane(p.ar_omega_min); pin_lane(p.ar_omega_max); pin_lane(p.ar_smoothing); pin_lane(p.ar_growth_rate);
+    pin_lane(p.ar_decay_rate); pin_lane(p.beta); pin_lane(p.overstep_min_step); pin_lane(p.hybrid_stuck_step_ratio);
+    pin_lane(p.hybrid_min_step); pin_lane(p.margin); pin_lane(p.ar_omega_init); pin_lane(p.overstep_bisection_steps);
+    pin_lane(p.hybrid_stuck_threshold); pin_lane(p.segment_bisection_steps); pin_lane(p.revaa_bisection_steps);
+}
+
+// Issue priority by ray age (RmFrameDesc.age_priority): built only when this is true.  Measured on the MI355X: no gain on
+// any scene (Sphere 0.47 ms, Cube 0.23, Mandelbulb 10.0-10.6 ms with or without), and its per-turn bookkeeping cost the
+// cheap scenes' render kernel 15 % more scalar instructions and the scalar registers that kept its output pointers
+// resident (Cube +6 %, Pillar Forest +8 % kernel time) -- so the field is accepted and ignored.
+constexpr bool kAgePriority = false;
+
 struct KernelArgs {
     FrameParams single;          // the frame of a one-frame launch (travels in the kernel arguments)
     const FrameParams* frames;   // device array [nframes] for batches, nullptr for one frame
@@ -93,6 +123,7 @@ struct KernelArgs {
     int32_t* evals;           // optional: SDF evaluations the march of every ray performed (needs cfg.full for the
                               // reference's count: its march() also evaluates for final_sdf)
     double* final_sdf;        // optional: MarchResult.final_sdf (needs cfg.full)
+    int32_t raw_outputs;      // any of t_raw / evals / final_sdf is set (the kernels test this before touching the pointers)
     long long* block_var;     // optional: (rows/4) x (width/8) variance numerators 32*sum(x^2)-sum(x)^2
     unsigned long long* stats;
     // Long-ray suspension (see resume_kernel): a ray still marching when its loop index reaches
@@ -128,6 +159,9 @@ __device__ __forceinline__ int rank_in_mask(unsigned long long m)
 
 // t_raw / final_sdf are parity-test outputs (fp64, every ray): written straight to global
 // memory when requested, never staged (they are not part of the 9 B/ray product path).
+// Callers test a per-lane copy of KernelArgs.raw_outputs first: a finished ray of the product path must not pull the
+// block of output pointers back into scalar registers (the compiler re-reads it from the kernel arguments at every
+// site that looks at one of these pointers).
 __device__ __forceinline__ void store_raw(const KernelArgs& a, uint32_t gi, const Result& r, int nev)
 {
     if (a.t_raw) a.t_raw[gi] = r.t;
@@ -150,16 +184,10 @@ __device__ __forceinline__ void rm_load_tables()
 {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(RM_TABLES_IN_LDS)
     constexpr unsigned tb = SceneTables<Scene>::value;
-    // re-laid-out mirrors (odd row strides, rm_tables.h)
+    // mirrors (row strides: rm_tables.h)
     if constexpr (tb & TB_POW) {
-        for (int i = threadIdx.x; i < 128 * kPowLogStride; i += blockDim.x) {
-            const int row = i / kPowLogStride, f = i - row * kPowLogStride;
-            rm_s_pow_log_tab[i] = rm_g_pow_log_tab[4 * row + (f ? f + 1 : 0)];
-        }
-        for (int i = threadIdx.x; i < 128 * kExpStride; i += blockDim.x) {
-            const int row = i / kExpStride, f = i - row * kExpStride;
-            rm_s_exp_tab[i] = f < 2 ? rm_g_exp_tab[2 * row + f] : 0ull;
-        }
+        for (int i = threadIdx.x; i < 128 * kPowLogStride; i += blockDim.x) rm_s_pow_log_tab[i] = rm_g_pow_log_tab[i];
+        for (int i = threadIdx.x; i < 128 * kExpStride; i += blockDim.x) rm_s_exp_tab[i] = rm_g_exp_tab[i];
     }
     if constexpr (tb & TB_SINCOS)
         for (int i = threadIdx.x; i < 110 * kSinCosStride; i += blockDim.x) {
@@ -341,7 +369,10 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
     int nev = 0;                                  // SDF evaluations this ray's march has performed
     vec3 origin = v3(0.0, 0.0, 0.0), dir = v3(0.0, 0.0, 0.0);
     MarchCfg lane_cfg = a.single.cfg;             // BATCH: of the frame this lane's ray belongs to
-    const MarchCfg& cfg = BATCH ? lane_cfg : a.single.cfg;
+    int raw_out = a.raw_outputs;                  // parity outputs requested (kept per lane, see store_raw)
+    pin_lane(raw_out);
+    if constexpr (!BATCH) pin_cfg(lane_cfg);      // one frame: per-lane copies of the kernel arguments (see pin_cfg)
+    const MarchCfg& cfg = lane_cfg;
     Strat s;
     typename EvalOf<Scene, INTERLEAVE>::type ev;  // INTERLEAVE: the SDF evaluation in flight
     bool ready = false;                           // INTERLEAVE: its value can be consumed
@@ -364,6 +395,9 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
                 const int gx = g.x0 + lane;
                 const bool col_ok = lane < g.tw;
                 long long bs = 0, bq = 0;   // per-column sums for the 8x4 block statistic
+                // the three output bases are read from the kernel arguments once per tile, not once per row
+                float* o_depth = a.depth; int32_t* o_iters = a.iters; uint8_t* o_hit = a.hit;
+                pin_lane(o_depth); pin_lane(o_iters); pin_lane(o_hit);
 #pragma unroll
                 for (int r = 0; r < TILE_H; ++r) {
                     if (r < g.th && col_ok) {
@@ -374,9 +408,9 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
                         if (ih != kSuspended) {     // a parked ray's pixel is written by resume_kernel
                             const int it = (int)(ih & 0x7fffffffu);
                             const int h = (int)(ih >> 31);
-                            a.depth[gi] = s_depth[k][li];
-                            a.iters[gi] = it;
-                            a.hit[gi] = (uint8_t)h;
+                            o_depth[gi] = s_depth[k][li];
+                            o_iters[gi] = it;
+                            o_hit[gi] = (uint8_t)h;
                             acc.add(it, h);
                             atomicAdd(&s_hist[min(it, a.hist_bins - 1)], 1u);
                             bs += it;
@@ -476,7 +510,7 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
                         if (s.start(cfg)) {
                             s_depth[cur][my_pix] = s.res.hit ? (float)s.res.t : 0.0f;
                             s_ih[cur][my_pix] = (uint32_t)s.res.iters | ((uint32_t)s.res.hit << 31);
-                            store_raw(a, my_gi, s.res, nev);
+                            if (raw_out) store_raw(a, my_gi, s.res, nev);
                             acc.evals += (unsigned)nev;
                         } else {
                             active = true;
@@ -497,7 +531,7 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
         // issue priority by age: a frame ends with its longest ray, and that ray's wave shares its SIMD with waves full
         // of short rays for most of the frame.  A wave raises its priority with the trip count of its oldest ray
         // (throughput-neutral: the other waves get the slots a dependent chain leaves free anyway).
-        if (a.age_prio > 0) {
+        if (kAgePriority && a.age_prio > 0) {
             int age = active ? s.i : 0;
             for (int off = 32; off > 0; off >>= 1) age = max(age, __shfl_xor(age, off));
             const int lvl = age / a.age_prio;
@@ -536,7 +570,7 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
                 fin = true;
                 s_depth[my_slot][my_pix] = s.res.hit ? (float)s.res.t : 0.0f;   // types.py:93
                 s_ih[my_slot][my_pix] = (uint32_t)s.res.iters | ((uint32_t)s.res.hit << 31);
-                store_raw(a, my_gi, s.res, nev);
+                if (raw_out) store_raw(a, my_gi, s.res, nev);
                 acc.evals += (unsigned)nev;
             } else if (a.suspend_after > 0 && s.i >= a.suspend_after) {
                 park = true;
@@ -562,7 +596,7 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
         }
         }
         // with age priority on, the scheduler also runs every 16 turns so an ageing ray is noticed without a finish
-        if (a.age_prio > 0 && ++since_sched >= 16) { since_sched = 0; dirty = true; }
+        if (kAgePriority && a.age_prio > 0 && ++since_sched >= 16) { since_sched = 0; dirty = true; }
         if constexpr (INTERLEAVE) {
             if (active && !ready) ready = Scene::trip(ev);
         }
@@ -614,7 +648,10 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void resume_kernel(const KernelAr
     int nev = 0;
     vec3 origin = v3(0.0, 0.0, 0.0), dir = v3(0.0, 0.0, 0.0);
     MarchCfg lane_cfg = a.single.cfg;             // BATCH: of the frame this lane's ray belongs to
-    const MarchCfg& cfg = BATCH ? lane_cfg : a.single.cfg;
+    int raw_out = a.raw_outputs;                  // parity outputs requested (kept per lane, see store_raw)
+    pin_lane(raw_out);
+    if constexpr (!BATCH) pin_cfg(lane_cfg);      // one frame: per-lane copies of the kernel arguments (see pin_cfg)
+    const MarchCfg& cfg = lane_cfg;
     Strat s;
     typename EvalOf<Scene, INTERLEAVE>::type ev;
     bool ready = false;
@@ -680,7 +717,7 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void resume_kernel(const KernelAr
                     a.depth[my_gi] = h ? (float)s.res.t : 0.0f;   // types.py:93
                     a.iters[my_gi] = it;
                     a.hit[my_gi] = (uint8_t)h;
-                    store_raw(a, my_gi, s.res, nev);
+                    if (raw_out) store_raw(a, my_gi, s.res, nev);
                     acc.evals += (unsigned)nev;
                     acc.add(it, h);
                     atomicAdd(&s_hist[min(it, a.hist_bins - 1)], 1u);
@@ -842,7 +879,10 @@ __global__ __launch_bounds__(64 * kTeam) void resume_team_kernel(const KernelArg
     int nev = 0;
     vec3 origin = v3(0.0, 0.0, 0.0), dir = v3(0.0, 0.0, 0.0);
     MarchCfg lane_cfg = a.single.cfg;             // BATCH: of the frame this lane's ray belongs to
-    const MarchCfg& cfg = BATCH ? lane_cfg : a.single.cfg;
+    int raw_out = a.raw_outputs;                  // parity outputs requested (kept per lane, see store_raw)
+    pin_lane(raw_out);
+    if constexpr (!BATCH) pin_cfg(lane_cfg);      // one frame: per-lane copies of the kernel arguments (see pin_cfg)
+    const MarchCfg& cfg = lane_cfg;
     Strat s;
     typename Scene::Eval ev;
     int turn = 0;
@@ -907,7 +947,7 @@ __global__ __launch_bounds__(64 * kTeam) void resume_team_kernel(const KernelArg
                 a.depth[my_gi] = h ? (float)s.res.t : 0.0f;   // types.py:93
                 a.iters[my_gi] = it;
                 a.hit[my_gi] = (uint8_t)h;
-                store_raw(a, my_gi, s.res, nev);
+                if (raw_out) store_raw(a, my_gi, s.res, nev);
                 acc.evals += (unsigned)nev;
                 acc.add(it, h);
                 atomicAdd(&s_hist[min(it, a.hist_bins - 1)], 1u);

@@ -131,6 +131,47 @@ RM_MATH_HD double rm_pow(double x, double y)
     return rm_pow_fix_special(x, rm_pow_exp_inline(ehi, elo));
 }
 
+// pow(x, 0.5) for a wavefront with FEW live lanes: the square root decides.
+//   s = sqrt(x) rounded, e = x - s*s (exact in one fma): the true root is s + e / (2 s).  glibc's pow returns the true
+//   value of x ** 0.5 with an error below 0.01 ulp BEFORE its final rounding (e_pow.c: exp 0.509 ulp after rounding, the
+//   log term contributes |y log x| 2^-15 ulp; measured on 1.4e9 arguments: pow(x, 0.5) != sqrt(x) only where the true
+//   root lies within 0.0088 ulp of a rounding midpoint, tests/test_math_exact.py), so it rounds to s whenever the true
+//   root is further than that from both midpoints around s.  The guard asks for 1/32 ulp (and a root that is not a
+//   power of two, where the spacing changes); it also rejects any s that is not the correctly rounded root, so
+//   nothing is assumed about the device's sqrt.  (x ** 2 yields to the same treatment -- product, fma residual -- and
+//   was measured: the cylinder scenes got slower, so it is not built.)  Lanes that fail the guard (6.25 % of spread-out
+//   arguments) take the full pow -- a WAVE-UNIFORM branch, which is why this form only pays when few lanes are live:
+//   the tail of a frame, where a handful of long rays march on in nearly empty wavefronts and every instruction is
+//   on the frame's critical chain (30 dependent instructions instead of 130).  Full wavefronts go straight to pow.
+// rm_pow_half_guard is the lane-local part, shared with the host check build.
+RM_MATH_HD double rm_pow_half_guard(double x, bool* safe)
+{
+    const double s = __builtin_sqrt(x);
+    const double e = rm_fma(-s, s, x);
+    const uint64_t sb = rm_asuint64(s);
+    const double u = rm_asdouble((sb & 0x7ff0000000000000ull) - (52ull << 52));     // ulp(s); x is far inside the normal range
+    *safe = (rm_fabs(e) < 0.9375 * (s * u)) & ((sb & 0x000fffffffffffffull) != 0) & (x > 0x1p-900) & (x < 0x1p900);
+    return s;
+}
+constexpr int kSparseLanes = 16;      // live lanes up to which the short forms are tried (fallback odds 1 - 0.9375^n: 64 % at 16)
+template <bool SPARSE>
+RM_MATH_HD double rm_pow_half(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (SPARSE) {
+        if (__popcll(__ballot(true)) <= kSparseLanes) {        // live lanes of this wave (wave-uniform)
+            bool safe;
+            double r = rm_pow_half_guard(x, &safe);
+            if (__any(!safe)) {
+                const double full = rm_pow(x, 0.5);
+                r = safe ? r : full;
+            }
+            return r;
+        }
+    }
+#endif
+    return rm_pow(x, 0.5);
+}
 // pow(x, ya) and pow(x, yb) sharing the one log(x) they both start from (catalog.py:280,283:
 // r ** 7.0 and r ** 8.0 of the same r); each result is bit-identical to a separate rm_pow call.
 RM_MATH_HD void rm_pow2(double x, double ya, double yb, double* ra, double* rb)

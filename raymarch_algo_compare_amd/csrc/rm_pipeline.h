@@ -265,7 +265,7 @@ __device__ __forceinline__ void store_direct(const KernelArgs& a, uint32_t gi, c
     a.depth[gi] = h ? (float)r.t : 0.0f;   // types.py:93
     a.iters[gi] = it;
     a.hit[gi] = (uint8_t)h;
-    store_raw(a, gi, r, nev);
+    if (a.raw_outputs) store_raw(a, gi, r, nev);
     acc.evals += (unsigned)nev;
     acc.add(it, h);
     atomicAdd(&s_hist[min(it, a.hist_bins - 1)], 1u);
@@ -335,7 +335,8 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
         int nev = 0;
         vec3 origin = v3(0.0, 0.0, 0.0), dir = v3(0.0, 0.0, 0.0);
         MarchCfg lane_cfg = a.single.cfg;
-        const MarchCfg& cfg = BATCH ? lane_cfg : a.single.cfg;
+        if constexpr (!BATCH) pin_cfg(lane_cfg);
+        const MarchCfg& cfg = lane_cfg;
         Strat s;
         typename Scene::Eval ev;
         int turn = 0;
@@ -475,7 +476,10 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
     int nev = 0;
     vec3 origin = v3(0.0, 0.0, 0.0), dir = v3(0.0, 0.0, 0.0);
     MarchCfg lane_cfg = a.single.cfg;
-    const MarchCfg& cfg = BATCH ? lane_cfg : a.single.cfg;
+    if constexpr (!BATCH) pin_cfg(lane_cfg);
+    const MarchCfg& cfg = lane_cfg;
+    int raw_out = a.raw_outputs;                  // parity outputs requested (kept per lane, see store_raw)
+    pin_lane(raw_out);
     Strat s;
     typename EvalOf<Scene, INTERLEAVE>::type ev;
     bool ready = false;
@@ -499,6 +503,9 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
                 const int gx = g.x0 + lane;
                 const bool col_ok = lane < g.tw;
                 long long bs = 0, bq = 0;
+                // the three output bases are read from the kernel arguments once per tile, not once per row
+                float* o_depth = a.depth; int32_t* o_iters = a.iters; uint8_t* o_hit = a.hit;
+                pin_lane(o_depth); pin_lane(o_iters); pin_lane(o_hit);
 #pragma unroll
                 for (int r = 0; r < TILE_H; ++r) {
                     if (r < g.th && col_ok) {
@@ -508,9 +515,9 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
                         if (ih != kSuspended) {
                             const int it = (int)(ih & 0x7fffffffu);
                             const int h = (int)(ih >> 31);
-                            a.depth[gi] = s_depth[k][li];
-                            a.iters[gi] = it;
-                            a.hit[gi] = (uint8_t)h;
+                            o_depth[gi] = s_depth[k][li];
+                            o_iters[gi] = it;
+                            o_hit[gi] = (uint8_t)h;
                             acc.add(it, h);
                             atomicAdd(&s_hist[min(it, a.hist_bins - 1)], 1u);
                             bs += it;
@@ -653,7 +660,7 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
                         if (s.start(cfg)) {
                             s_depth[cur][my_pix] = s.res.hit ? (float)s.res.t : 0.0f;
                             s_ih[cur][my_pix] = (uint32_t)s.res.iters | ((uint32_t)s.res.hit << 31);
-                            store_raw(a, my_gi, s.res, nev);
+                            if (raw_out) store_raw(a, my_gi, s.res, nev);
                             acc.evals += (unsigned)nev;
                         } else {
                             active = true;
@@ -672,7 +679,7 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
 
         // ---- 2a. issue priority by age: a wave that carries an old ray (a candidate for the frame's longest chain)
         // wins the arbitration against the wave it shares its SIMD with; throughput-neutral among producers
-        if (a.age_prio > 0) {
+        if (kAgePriority && a.age_prio > 0) {
             int age = active ? s.i : 0;
             for (int off = 32; off > 0; off >>= 1) age = max(age, __shfl_xor(age, off));
             const int lvl = age / a.age_prio;
@@ -745,7 +752,7 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
                     fin = true;
                     s_depth[my_slot][my_pix] = s.res.hit ? (float)s.res.t : 0.0f;   // types.py:93
                     s_ih[my_slot][my_pix] = (uint32_t)s.res.iters | ((uint32_t)s.res.hit << 31);
-                    store_raw(a, my_gi, s.res, nev);
+                    if (raw_out) store_raw(a, my_gi, s.res, nev);
                     acc.evals += (unsigned)nev;
                 }
             } else if (!nopark && ((!resumed && park0 > 0 && s.i >= park0) || (resumed && park1 > 0 && s.i >= park1))) {

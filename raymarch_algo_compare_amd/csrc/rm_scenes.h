@@ -33,17 +33,17 @@ RM_HD double sd_plane(vec3 p, vec3 n, double offset) { return dot(p, n) - offset
 
 RM_HD double sd_cylinder(vec3 p, double radius, double half_height)                      // :23-28
 {
-    double d_radial = rm_pow(p.x * p.x + p.z * p.z, 0.5) - radius;
+    double d_radial = pow_half(p.x * p.x + p.z * p.z) - radius;
     double d_height = rm_fabs(p.y) - half_height;
-    double outside = rm_pow(rm_pow(py_max(d_radial, 0.0), 2.0) + rm_pow(py_max(d_height, 0.0), 2.0), 0.5);
+    double outside = pow_half(rm_pow(py_max(d_radial, 0.0), 2.0) + rm_pow(py_max(d_height, 0.0), 2.0));
     double inside = py_min(py_max(d_radial, d_height), 0.0);
     return outside + inside;
 }
 
 RM_HD double sd_torus(vec3 p, double major_radius, double minor_radius)                  // :30-32
 {
-    double q_xz = rm_pow(p.x * p.x + p.z * p.z, 0.5) - major_radius;
-    return rm_pow(q_xz * q_xz + p.y * p.y, 0.5) - minor_radius;
+    double q_xz = pow_half_a(p.x * p.x + p.z * p.z) - major_radius;
+    return pow_half_a(q_xz * q_xz + p.y * p.y) - minor_radius;
 }
 
 RM_HD double sd_capped_torus(vec3 p, double sc0, double sc1, double ra, double rb)       // :41-50
@@ -53,8 +53,8 @@ RM_HD double sd_capped_torus(vec3 p, double sc0, double sc1, double ra, double r
     if (sc1 * px > sc0 * p.y)
         k = px * sc0 + p.y * sc1;
     else
-        k = rm_pow(px * px + p.y * p.y, 0.5);
-    return rm_pow(p.x * p.x + p.y * p.y + p.z * p.z + ra * ra - 2.0 * ra * k, 0.5) - rb;
+        k = pow_half_a(px * px + p.y * p.y);
+    return pow_half_a(p.x * p.x + p.y * p.y + p.z * p.z + ra * ra - 2.0 * ra * k) - rb;
 }
 
 RM_HD double op_smooth_union(double d1, double d2, double k)                             // :80-86
@@ -155,7 +155,7 @@ struct SceneMandelbulb {                                                        
     static RM_HD bool begin(Eval& e, vec3 p)
     {
         e.p = p; e.z = p; e.dr = 1.0; e.i = 0;
-        e.r = length(p);
+        e.r = length_a(p);
         return e.r > 4.0;
     }
     // the body of one trip of `for i in range(8)` (:276-290) followed by the loop test and the next
@@ -181,7 +181,7 @@ struct SceneMandelbulb {                                                        
         rm_sincos(phi, &sp, &cp);
         e.z = v3(zr * st * cp, zr * st * sp, zr * ct) + e.p;
         if (++e.i >= 8) return true;                    // r keeps the length measured before this update
-        e.r = length(e.z);
+        e.r = length_a(e.z);
         return e.r > 4.0;
     }
     // ---- the trip split by function, for a TEAM of wavefronts (rm_kernels.h) ----------------------
@@ -214,7 +214,7 @@ struct SceneMandelbulb {                                                        
         e.dr = r7 * power * e.dr + 1.0;
         e.z = v3(zr * st * cp, zr * st * sp, zr * ct) + e.p;
         if (++e.i >= 8) return true;
-        e.r = length(e.z);
+        e.r = length_a(e.z);
         return e.r > 4.0;
     }
     static RM_HD double value(const Eval& e)

@@ -5,6 +5,8 @@
 
 extern "C" {
 void rmc_pow(const double* x, const double* y, size_t n, double* out) { for (size_t i = 0; i < n; ++i) out[i] = rm::rm_pow(x[i], y[i]); }
+// lane-local part of rm_pow_half: the rounded square root and whether the guard lets it stand for pow(x, 0.5)
+void rmc_pow_half_guard(const double* x, size_t n, double* root, unsigned char* safe) { for (size_t i = 0; i < n; ++i) { bool ok; root[i] = rm::rm_pow_half_guard(x[i], &ok); safe[i] = ok; } }
 void rmc_pow2(const double* x, size_t n, double ya, double yb, double* oa, double* ob) { for (size_t i = 0; i < n; ++i) rm::rm_pow2(x[i], ya, yb, &oa[i], &ob[i]); }
 void rmc_sin(const double* x, size_t n, double* out) { for (size_t i = 0; i < n; ++i) out[i] = rm::rm_sin(x[i]); }
 void rmc_cos(const double* x, size_t n, double* out) { for (size_t i = 0; i < n; ++i) out[i] = rm::rm_cos(x[i]); }

@@ -52,6 +52,42 @@ def test_pow_exact(m, y):
         assert _bits_equal(_call2(m, "rmc_pow", x, yy), _call2(m, "rml_pow", x, yy)) == 0
 
 
+def test_pow_half_guard_only_passes_roots_that_pow_returns(m):
+    """rm_pow_half (team wavefronts): wherever the guard accepts the rounded square root, libm's pow(x, 0.5) returns
+    exactly that value; it refuses ~1/16 of spread-out arguments, every argument on which pow and sqrt differ (those lie
+    within 0.009 ulp of a rounding midpoint, the guard band is 1/32 ulp), roots that are powers of two, and the edges
+    of the exponent range."""
+    rng = np.random.default_rng(5)
+    dp = ctypes.POINTER(ctypes.c_double)
+    m.rmc_pow_half_guard.argtypes = [dp, ctypes.c_size_t, dp, ctypes.POINTER(ctypes.c_ubyte)]
+    v = rng.uniform(-4, 4, (4 * N, 3))
+    sets = [rng.uniform(0, 40.0, 8 * N), np.exp(rng.uniform(-60, 8, 8 * N)), (v * v).sum(1), rng.uniform(0.999, 1.001, N),
+            np.ldexp(rng.uniform(0.5, 1.0, 4 * N), rng.integers(-40, 12, 4 * N))]
+    differ = refused = total = 0
+    for x in sets:
+        root, safe = np.empty_like(x), np.empty(len(x), np.uint8)
+        m.rmc_pow_half_guard(x.ctypes.data_as(dp), len(x), root.ctypes.data_as(dp), safe.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)))
+        ref = _call2(m, "rml_pow", x, np.full(len(x), 0.5))
+        ne = root.view(np.uint64) != ref.view(np.uint64)
+        assert not (ne & (safe != 0)).any()
+        differ += int(ne.sum()); refused += int((safe == 0).sum()); total += len(x)
+    assert differ > 1000                                   # the cases the guard exists for were exercised
+    assert 0.055 < refused / total < 0.07
+    # how far from a rounding midpoint the arguments on which pow and sqrt differ lie: well inside the 1/32-ulp band
+    x = rng.uniform(1.0, 4.0, 16 * N)
+    root, safe = np.empty_like(x), np.empty(len(x), np.uint8)
+    m.rmc_pow_half_guard(x.ctypes.data_as(dp), len(x), root.ctypes.data_as(dp), safe.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)))
+    ne = root.view(np.uint64) != _call2(m, "rml_pow", x, np.full(len(x), 0.5)).view(np.uint64)
+    xs, rs = x[ne].astype(np.longdouble), root[ne].astype(np.longdouble)
+    dist = 0.5 - np.abs(xs - rs * rs) / (2 * rs * np.longdouble(2.0) ** -52)      # roots in [1, 2): ulp = 2^-52
+    assert ne.sum() > 100 and float(dist.max()) < 1.0 / 64
+    # never accepted: zero, subnormal / huge arguments, non-finite, exact powers of four (root = a power of two)
+    x = np.array([0.0, 5e-324, 1e-310, 1e-300, 1e300, np.inf, np.nan, 4.0, 1.0, 0.25, 16.0, 2.0 ** -40])
+    root, safe = np.empty_like(x), np.empty(len(x), np.uint8)
+    m.rmc_pow_half_guard(x.ctypes.data_as(dp), len(x), root.ctypes.data_as(dp), safe.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)))
+    assert not safe.any()
+
+
 def test_pow2_shares_the_log_exactly(m):
     rng = np.random.default_rng(8)
     dp = ctypes.POINTER(ctypes.c_double)
