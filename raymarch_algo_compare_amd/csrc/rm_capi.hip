@@ -332,16 +332,15 @@ void suspend_levels(const RmFrameDesc* d, long long rays, int mode, int* park)
         d->march.max_iterations > 128)
         park[0] = 128;
     // Sphere Cloud and Bumpy Sphere (unions of 24 / 31 spheres: a pow per sphere and evaluation).  The long rays are
-    // parked at 16 trips and finished by TEAMS, each wave taking a third of the sphere list: 4.03 -> 3.2 ms and
-    // 6.5 -> 5.2 ms (Curvature 7.9 -> 5.7).
-    if ((d->scene_id == 14 || d->scene_id == 15) && strat_ok && d->suspend_after[0] == 0 && rays <= 16000000ll &&
-        d->march.max_iterations > 128)
+    // parked at 16 trips and finished by TEAMS, each wave taking a third of the sphere list: 3.8 -> 3.0 ms and
+    // 6.4 -> 5.0-5.2 ms (Curvature 6.7 -> 5.6, Segment 7.3 -> 5.7).  Not for Adaptive-Hybrid, whose rays end early
+    // (2.33 vs 1.88 ms and 3.23 vs 3.10 without).
+    if ((d->scene_id == 14 || d->scene_id == 15) && strat_ok && d->strategy_id != 9 && d->suspend_after[0] == 0 &&
+        rays <= 16000000ll && d->march.max_iterations > 128)
         park[0] = 16 / two;
-    // Gyroid (three sincos per evaluation, long skimming rays inside the ball): parking at 24 trips measured
-    // 1.88 -> 1.63 ms (Standard), 2.32 -> 2.01 (Curvature), 2.13 -> 1.72 (Enhanced); slower for Segment, and a
-    // team form (one sincos per wave) measured slower than single waves -- the evaluation is too short for it.
-    if (d->scene_id == 16 && strat_ok && two == 1 && d->suspend_after[0] == 0 && rays <= 16000000ll && d->march.max_iterations > 128)
-        park[0] = 24;
+    // Gyroid (three sincos per evaluation, long skimming rays inside the ball) parked at 24 trips in round 1 (1.88 ->
+    // 1.63 ms in natural tile order).  With the centre-out order its long rays start early anyway: parking measured
+    // 1.63 vs 1.60 ms without (Adaptive-Hybrid 1.17 vs 1.05), so it no longer parks.
     // Single launch (Mandelbulb): rays are struck from their tile at 16 trips (the tile slot is free again) and handed
     // to the teams at 48; larger frames, and Segment whose trips evaluate twice, at 32 / 64.  Every strategy gains,
     // Overstep-Bisect and Skipping-Spheres included (3.56 -> 3.08 ms, 11.3 -> 10.2 ms).
