@@ -33,6 +33,12 @@ extern "C" {
 
 #define RM_NUM_SCENES 20
 #define RM_NUM_STRATEGIES 11
+/* Strategy ids [0, RM_NUM_STRATEGIES) are the reference's CPU registry (strategies/__init__.py:16-28).  Two more exist
+ * only in its fragment shader (gpu/shaders/strategies.glsl:508-541 safe_relaxed = 11, :559-593 dense_march = 12; shader
+ * ids 8 and 9): here they run the shader's control flow on the CPU path's arithmetic (binary64, this camera).  PARITY
+ * UNPINNED: no Python statement of them exists and the shader computes in fp32, so nothing of the reference can check
+ * them; they are not part of the registry (rm_num_strategies() stays 11, names / CLI "all" unchanged). */
+#define RM_NUM_STRATEGY_KERNELS 13
 #define RM_HIST_BINS 544 /* iterations histogram bins; counts >= RM_HIST_BINS-1 share the last bin */
 #define RM_MAX_TIMED 256
 
@@ -60,6 +66,11 @@ typedef struct RmStrategyParams {
     int32_t hybrid_stuck_threshold;   /* 5       stuck_threshold)                           strategies/adaptive_hybrid.py:17 */
     int32_t segment_bisection_steps;  /* 8     SegmentTracing: the literal `range(8)` of march()      segment_tracing.py:79 */
     int32_t revaa_bisection_steps;    /* 8     RevAAApproxTracing: the literal `range(8)` of march()  rev_affine.py:70 */
+    /* shader-only uniforms (the CPU strategies have no such constant; defaults change no bit of the registry's results) */
+    double step_scale;                /* 1.0   `stepScale`: standard() multiplies every step by it (strategies.glsl:24,47 -- the
+                                               understep oracle of gpu/groundtruth.py:59-61 uses 0.6), dense_march() too (:570) */
+    double dense_min_step;            /* 1e-4  `minStep` as dense_march reads it (strategies.glsl:570; the seam's default is
+                                               max(hit_threshold, min_step_fraction * max_distance), gpu/runner.py:117-118) */
 } RmStrategyParams;
 
 /* MarchConfig (config.py:19-29) -- the three fields the CPU strategies read -- plus

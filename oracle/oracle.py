@@ -43,6 +43,7 @@ PARAM_FIELDS = [
     ("ar_omega_init", ctypes.c_double, 1.2),
     ("overstep_bisection_steps", ctypes.c_int32, 16), ("hybrid_stuck_threshold", ctypes.c_int32, 5),
     ("segment_bisection_steps", ctypes.c_int32, 8), ("revaa_bisection_steps", ctypes.c_int32, 8),
+    ("step_scale", ctypes.c_double, 1.0), ("dense_min_step", ctypes.c_double, 1e-4),      # shader-only uniforms
 ]
 DEFAULT_PARAMS = {n: d for n, _, d in PARAM_FIELDS}
 

@@ -320,6 +320,9 @@ typedef struct {
     int32_t hybrid_stuck_threshold;   /* stuck_threshold=5)                             adaptive_hybrid.py:17 */
     int32_t segment_bisection_steps;  /* `range(8)`, a literal of SegmentTracing.march  segment_tracing.py:79 */
     int32_t revaa_bisection_steps;    /* `range(8)`, a literal of RevAAApproxTracing.march  rev_affine.py:70 */
+    /* uniforms only the reference's fragment shader has */
+    double step_scale;                /* `stepScale` (1.0): standard() and dense_march()   gpu/shaders/strategies.glsl:24,47,570 */
+    double dense_min_step;            /* `minStep` as dense_march reads it                 gpu/shaders/strategies.glsl:570 */
 } rmo_cfg;
 
 typedef struct { int hit; double t; int32_t iterations; double final_sdf; } result_t;
@@ -337,7 +340,7 @@ static result_t st_standard(const ray_t *ray, sdf_fn sdf, const rmo_cfg *c)
         iterations = i + 1;
         double d = sdf(ray_at(ray, t));
         if (fabs(d) < c->hit_threshold) return mk(1, t, iterations, d);
-        t += d;
+        t += d * c->step_scale;      /* standard_sphere.py:41 `t += d`; the shader's stepScale (strategies.glsl:47), 1.0 by default */
         if (t > c->max_distance) break;
     }
     return mk(0, t, iterations, sdf(ray_at(ray, t)));
@@ -636,12 +639,69 @@ static result_t st_revaa(const ray_t *ray, sdf_fn sdf, const rmo_cfg *c)
     return mk(0, t, iterations, sdf(ray_at(ray, t)));
 }
 
+/* ---- the two strategies that exist only in the reference's fragment shader ----------------------------------
+ * PARITY UNPINNED: there is no Python statement of them and the shader computes in fp32 (moderngl is absent here), so
+ * no fixture of the reference pins these two functions.  They restate the shader text in binary64 on this camera;
+ * what the tests check with them is that the HIP state machines follow the same text. */
+
+/* gpu/shaders/strategies.glsl:508-541 safe_relaxed */
+static result_t st_safe_relaxed(const ray_t *ray, sdf_fn sdf, const rmo_cfg *c)
+{
+    double t = 0.0, omega_eff = c->omega, prev_radius = 0.0, step_length = 0.0, d = 0.0;
+    int32_t it = 0;
+    for (int32_t i = 0; i < c->max_iterations; ++i) {
+        it = i + 1;
+        d = sdf(ray_at(ray, t));
+        double radius = fabs(d);
+        int sor_fail = (omega_eff > 1.0) && ((radius + prev_radius) < step_length);
+        if (sor_fail) { step_length -= omega_eff * step_length; omega_eff = 1.0; }
+        else step_length = d * omega_eff;
+        prev_radius = radius;
+        if (!sor_fail && radius < c->hit_threshold) return mk(1, t, it, d);
+        t += step_length;
+        if (t > c->max_distance) break;
+        if (t < 0.0) t = 0.0;
+    }
+    return mk(0, t, it, d);
+}
+
+/* gpu/shaders/strategies.glsl:559-593 dense_march */
+static result_t st_dense_march(const ray_t *ray, sdf_fn sdf, const rmo_cfg *c)
+{
+    int32_t it = 1;
+    double t = 0.0;
+    double d = sdf(ray_at(ray, 0.0));
+    if (fabs(d) < c->hit_threshold) return mk(1, t, it, d);
+    for (int32_t i = 1; i < c->max_iterations; ++i) {
+        it = i + 1;
+        double prev_t = t, prev_d = d;
+        double sc = d * c->step_scale;
+        double step = (sc < c->dense_min_step) ? c->dense_min_step : sc;     /* max(d * stepScale, minStep) */
+        t += step;
+        if (t > c->max_distance) break;
+        d = sdf(ray_at(ray, t));
+        if (prev_d > 0.0 && d <= 0.0) {
+            double a = prev_t, b = t;
+            for (int j = 0; j < 30; ++j) {
+                double mid = 0.5 * (a + b);
+                double dm = sdf(ray_at(ray, mid));
+                if (dm > 0.0) a = mid; else b = mid;
+            }
+            double tm = 0.5 * (a + b);
+            return mk(1, tm, it, sdf(ray_at(ray, tm)));
+        }
+        if (fabs(d) < c->hit_threshold) return mk(1, t, it, d);
+    }
+    return mk(0, t, it, d);
+}
+
 typedef result_t (*strat_fn)(const ray_t *, sdf_fn, const rmo_cfg *);
-#define RMO_NUM_STRATEGIES 11
-/* order == STRATEGIES dict (strategies/__init__.py:16-28) */
+#define RMO_NUM_STRATEGIES 13
+/* [0, 11): order == STRATEGIES dict (strategies/__init__.py:16-28); 11, 12: the shader-only two (unpinned, above) */
 static const strat_fn STRATS[RMO_NUM_STRATEGIES] = {
     st_standard, st_relaxed, st_auto_relaxed, st_slope, st_enhanced, st_curvature,
     st_overstep_bisect, st_skipping, st_revaa, st_hybrid, st_segment,
+    st_safe_relaxed, st_dense_march,
 };
 
 /* ---- camera (core/camera.py:35-41) + frame loop (metrics/collector.py:40-44) */

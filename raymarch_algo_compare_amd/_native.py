@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "librm_hip.so")
 
 RM_NUM_SCENES = 20
 RM_NUM_STRATEGIES = 11
+RM_NUM_STRATEGY_KERNELS = 13      # + the two shader-only strategies (ids 11, 12; parity unpinned)
 RM_HIST_BINS = 544
 RM_MAX_TIMED = 256
 
@@ -49,6 +50,8 @@ STRATEGY_PARAM_FIELDS = [
     ("ar_omega_init", ctypes.c_double, 1.2),
     ("overstep_bisection_steps", ctypes.c_int32, 16), ("hybrid_stuck_threshold", ctypes.c_int32, 5),
     ("segment_bisection_steps", ctypes.c_int32, 8), ("revaa_bisection_steps", ctypes.c_int32, 8),
+    # uniforms only the reference's fragment shader has (strategies.glsl:24,47,570); the defaults change no bit
+    ("step_scale", ctypes.c_double, 1.0), ("dense_min_step", ctypes.c_double, 1e-4),
 ]
 DEFAULT_STRATEGY_PARAMS = {n: d for n, _, d in STRATEGY_PARAM_FIELDS}
 

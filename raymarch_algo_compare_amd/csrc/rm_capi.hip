@@ -19,7 +19,7 @@
 #include "rm_pipeline.h"
 
 static_assert(RM_HIST_BINS == rm::kHistBins, "histogram size mismatch between ABI and kernels");
-static_assert(RM_NUM_SCENES == 20 && RM_NUM_STRATEGIES == 11, "registry size");
+static_assert(RM_NUM_SCENES == 20 && RM_NUM_STRATEGIES == 11 && RM_NUM_STRATEGY_KERNELS == 13, "registry size");
 
 namespace rm {
 #define RM_X(id, S) const SceneLaunchers* scene_launchers_##id();
@@ -122,7 +122,7 @@ int check_desc(const RmFrameDesc* d)
 {
     if (!d) return fail(RM_E_BAD_ARG, "desc is NULL");
     if (d->scene_id < 0 || d->scene_id >= RM_NUM_SCENES) return fail(RM_E_BAD_SCENE, "scene_id %d out of range", d->scene_id);
-    if (d->strategy_id < 0 || d->strategy_id >= RM_NUM_STRATEGIES)
+    if (d->strategy_id < 0 || d->strategy_id >= RM_NUM_STRATEGY_KERNELS)
         return fail(RM_E_BAD_STRATEGY, "strategy_id %d out of range", d->strategy_id);
     if (d->width <= 0 || d->height <= 0 || d->row0 < 0 || d->rows < 0 ||
         (!(d->band_rows > 0 && d->band_stride > 1) && d->row0 + d->rows > d->height))
@@ -846,7 +846,7 @@ static int march_rays_impl(bool team, int scene_id, int strategy_id, const RmMar
     int rc = check_ready();
     if (rc) return rc;
     if (scene_id < 0 || scene_id >= RM_NUM_SCENES) return fail(RM_E_BAD_SCENE, "scene_id %d out of range", scene_id);
-    if (strategy_id < 0 || strategy_id >= RM_NUM_STRATEGIES)
+    if (strategy_id < 0 || strategy_id >= RM_NUM_STRATEGY_KERNELS)
         return fail(RM_E_BAD_STRATEGY, "strategy_id %d out of range", strategy_id);
     if (!cfg) return fail(RM_E_BAD_ARG, "cfg is NULL");
     if (team && !rm::scene(scene_id)->march_rays_team) return fail(RM_E_BAD_SCENE, "scene %d has no wavefront-team form", scene_id);

@@ -94,6 +94,8 @@ struct StratParams {
     int32_t hybrid_stuck_threshold;     //   stuck_threshold=5,                       adaptive_hybrid.py:17
     int32_t segment_bisection_steps;    // `range(8)` in SegmentTracing.march         segment_tracing.py:79
     int32_t revaa_bisection_steps;      // `range(8)` in RevAAApproxTracing.march     rev_affine.py:70
+    double step_scale;               // `stepScale` uniform: standard / dense_march (1.0)   gpu/shaders/strategies.glsl:24,47,570
+    double dense_min_step;           // `minStep` uniform as dense_march reads it (1e-4)    gpu/shaders/strategies.glsl:570
 };
 
 RM_HD StratParams default_strat_params()
@@ -107,6 +109,7 @@ RM_HD StratParams default_strat_params()
     p.margin = 0.05;
     p.ar_omega_init = 1.2;
     p.overstep_bisection_steps = 16; p.hybrid_stuck_threshold = 5; p.segment_bisection_steps = 8; p.revaa_bisection_steps = 8;
+    p.step_scale = 1.0; p.dense_min_step = 1e-4;
     return p;
 }
 

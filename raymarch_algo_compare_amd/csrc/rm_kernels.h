@@ -95,6 +95,7 @@ __device__ __forceinline__ void pin_cfg(MarchCfg& c)
     pin_lane(p.ar_decay_rate); pin_lane(p.beta); pin_lane(p.overstep_min_step); pin_lane(p.hybrid_stuck_step_ratio);
     pin_lane(p.hybrid_min_step); pin_lane(p.margin); pin_lane(p.ar_omega_init); pin_lane(p.overstep_bisection_steps);
     pin_lane(p.hybrid_stuck_threshold); pin_lane(p.segment_bisection_steps); pin_lane(p.revaa_bisection_steps);
+    pin_lane(p.step_scale); pin_lane(p.dense_min_step);
 }
 
 // Issue priority by ray age (RmFrameDesc.age_priority): built only when this is true.  Measured on the MI355X: no gain on

@@ -1,4 +1,5 @@
-// rm_strategies.h -- the 11 marching strategies as resumable state machines.
+// rm_strategies.h -- the 11 marching strategies of the CPU registry (+ the two that exist only in the reference's
+// fragment shader) as resumable state machines.
 //
 // The reference strategies are Python loops that call sdf() at several places
 // (strategies/*.py).  Here each strategy is a small per-lane state record with
@@ -83,7 +84,9 @@ struct StratStandard : StratBase {
         if (phase == PH_TAIL) { res.final_sdf = d; return true; }
         it = i + 1;
         if (rm_fabs(d) < c.hit_threshold) return finish(1, t, d);
-        t += d;
+        // `t += d`; the shader's standard() scales the step by its stepScale uniform (strategies.glsl:47; the
+        // understep oracle of gpu/groundtruth.py:59-61 sets 0.6).  d * 1.0 is d: the default changes no bit.
+        t += d * c.prm.step_scale;
         if (t > c.max_distance) return finish_miss(c);
         return next_iter(c);
     }
@@ -520,13 +523,107 @@ struct StratSegment : StratBase {
     }
 };
 
+// ---- the two strategies that exist only in the reference's fragment shader --------------------------------------
+// No Python statement of them exists; these are the shader's control flow on the CPU path's
+// arithmetic (binary64, this engine's camera): PARITY UNPINNED -- nothing of the reference can check them here
+// (moderngl is absent and the shader computes in fp32).  The oracle restates the same text, so GPU == oracle holds.
+// A miss reports the LAST evaluated distance as final_sdf, as the shader does (no tail evaluation).
+
+// 11: gpu/shaders/strategies.glsl:508-541  safe_relaxed (Keinert et al. 2014), uniform `omega`
+struct StratSafeRelaxed : StratBase {
+    double omega_eff, prev_radius, step_length, last_d;
+    RM_HD bool start(const MarchCfg& c)
+    {
+        omega_eff = c.prm.omega; prev_radius = 0.0; step_length = 0.0; last_d = 0.0;
+        t = 0.0; i = 0; it = 0;
+        if (c.max_iterations <= 0) return finish(0, t, last_d);
+        te = t; phase = PH_MAIN;
+        return false;
+    }
+    RM_HD bool step(double d, const MarchCfg& c)
+    {
+        it = i + 1;
+        last_d = d;
+        const double radius = rm_fabs(d);
+        // disjoint-sphere test: the spheres at the previous and the current point must cover the step just taken
+        const bool sor_fail = (omega_eff > 1.0) && ((radius + prev_radius) < step_length);
+        if (sor_fail) {
+            step_length -= omega_eff * step_length;       // undo the over-relaxation
+            omega_eff = 1.0;
+        } else {
+            step_length = d * omega_eff;
+        }
+        prev_radius = radius;
+        if (!sor_fail && radius < c.hit_threshold) return finish(1, t, d);
+        t += step_length;
+        if (t > c.max_distance) return finish(0, t, d);
+        if (t < 0.0) t = 0.0;
+        ++i;
+        if (i >= c.max_iterations) return finish(0, t, d);
+        te = t;
+        return false;
+    }
+};
+
+// 12: gpu/shaders/strategies.glsl:559-593  dense_march (calibration oracle), uniforms `stepScale`, `minStep`
+struct StratDenseMarch : StratBase {
+    double prev_t, prev_d, lo, hi, d_cur;
+    int32_t k;
+    RM_HD bool start(const MarchCfg& c)
+    {
+        t = 0.0; i = 0; it = 1; d_cur = 0.0;
+        te = 0.0; phase = PH_A;                            // the sample at t = 0
+        (void)c;
+        return false;
+    }
+    RM_HD bool advance(const MarchCfg& c)                  // top of `for (int i = 1; i < maxIterations; i++)`
+    {
+        ++i;
+        if (i >= c.max_iterations) return finish(0, t, d_cur);
+        it = i + 1;
+        prev_t = t; prev_d = d_cur;
+        const double sc = d_cur * c.prm.step_scale;
+        t += (sc < c.prm.dense_min_step) ? c.prm.dense_min_step : sc;      // max(d * stepScale, minStep)
+        if (t > c.max_distance) return finish(0, t, d_cur);
+        te = t; phase = PH_MAIN;
+        return false;
+    }
+    RM_HD bool step(double d, const MarchCfg& c)
+    {
+        if (phase == PH_TAIL) { res.final_sdf = d; return true; }
+        if (phase == PH_A) {
+            d_cur = d;
+            if (rm_fabs(d) < c.hit_threshold) return finish(1, t, d);
+            i = 0;
+            return advance(c);
+        }
+        if (phase == PH_MAIN) {
+            d_cur = d;
+            if (prev_d > 0.0 && d <= 0.0) {               // entered the surface between prev_t and t: bisect
+                lo = prev_t; hi = t; k = 0;
+                te = 0.5 * (lo + hi); phase = PH_B;
+                return false;
+            }
+            if (rm_fabs(d) < c.hit_threshold) return finish(1, t, d);
+            return advance(c);
+        }
+        // PH_B: 30 halvings of [lo (outside), hi (inside)]
+        if (d > 0.0) lo = te; else hi = te;
+        if (++k < 30) { te = 0.5 * (lo + hi); return false; }
+        return finish_hit_reeval(0.5 * (lo + hi), c);      // final_sdf = map at the midpoint (one more evaluation)
+    }
+};
+
 #define RM_NUM_STRATEGIES 11
 
 // X(id, functor) in registry order
 #define RM_STRATEGY_LIST(X)                                                                 \
     X(0, StratStandard) X(1, StratRelaxed) X(2, StratAutoRelaxed) X(3, StratSlope)          \
     X(4, StratEnhanced) X(5, StratCurvature) X(6, StratOverstepBisect) X(7, StratSkipping)  \
-    X(8, StratRevAA) X(9, StratHybrid) X(10, StratSegment)
+    X(8, StratRevAA) X(9, StratHybrid) X(10, StratSegment)                                  \
+    X(11, StratSafeRelaxed) X(12, StratDenseMarch)
+// ids [0, RM_NUM_STRATEGIES) are the CPU registry; [RM_NUM_STRATEGIES, RM_NUM_STRATEGY_KERNELS) the shader-only two
+#define RM_NUM_STRATEGY_KERNELS 13
 
 // March one ray to completion (no lane refill): used by rm_march_rays and the host check.
 template <class Scene, class Strat>

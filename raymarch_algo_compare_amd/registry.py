@@ -98,6 +98,15 @@ _STRATEGY_ROWS = [
     ("Segment", "Segment", "Segment Tracing", True),
 ]
 STRATEGIES = {row[0]: i for i, row in enumerate(_STRATEGY_ROWS)}   # key -> strategy id
+# Strategies that exist only in the reference's fragment shader (gpu/shaders/strategies.glsl:508-541, :559-593; shader
+# ids 8 and 9).  Kernel ids 11 and 12: the shader's control flow on the CPU path's arithmetic -- PARITY UNPINNED (no
+# Python statement exists, the shader is fp32).  Not registry entries: `list_strategies()`, `--strategy all` and the
+# CSV columns stay the reference's eleven; they are reached by key through get_shader_strategy / GPURunner.
+_SHADER_ONLY_ROWS = [
+    ("Safe-Relaxed", "Safe-Relaxed(ω=1.2)", "Safe Over-Relaxed Sphere Tracing (ω=1.2)", False),
+    ("Dense-March", "Dense-March", "Dense March (calibration oracle)", False),
+]
+SHADER_ONLY_STRATEGIES = {row[0]: len(_STRATEGY_ROWS) + i for i, row in enumerate(_SHADER_ONLY_ROWS)}
 
 # The nine strategies of the reference README (README.md:7-15) and the 14 scenes of its
 # published matrix (example/matrix_*.csv) -- the graded 14 x 9 configuration.
@@ -183,6 +192,25 @@ def get_strategy_by_name(name: str, **ctor) -> Optional[StrategyInfo]:
     for i, row in enumerate(_STRATEGY_ROWS):
         if row[1].lower() == low:
             return _make_strategy(i, **ctor)
+    return None
+
+
+def get_shader_strategy(key: str, **params) -> Optional[StrategyInfo]:
+    """One of the two shader-only strategies ("Safe-Relaxed": omega; "Dense-March": step_scale, dense_min_step) as a
+    StrategyInfo whose id is the kernel id; `params` are RmStrategyParams names.  None for any other key."""
+    low = key.lower().replace("_", "-")
+    for i, row in enumerate(_SHADER_ONLY_ROWS):
+        if row[0].lower() == low:
+            st = StrategyInfo(len(_STRATEGY_ROWS) + i, row[0], row[1], row[2], row[3])
+            allowed = {"Safe-Relaxed": ("omega",), "Dense-March": ("step_scale", "dense_min_step")}[row[0]]
+            for k, v in params.items():
+                if k not in allowed:
+                    raise TypeError(f"{row[0]}: unexpected parameter {k!r} (accepted: {list(allowed)})")
+                st.params[k] = v
+            if row[0] == "Safe-Relaxed" and "omega" in st.params:
+                w = st.params["omega"]
+                st.short_name, st.name = f"Safe-Relaxed(ω={w})", f"Safe Over-Relaxed Sphere Tracing (ω={w})"
+            return st
     return None
 
 

@@ -15,7 +15,7 @@ import numpy as np
 from . import _native
 from .camera import Camera
 from .config import MarchConfig, RenderConfig
-from .registry import SCENES, get_strategy_by_name
+from .registry import SCENES, get_shader_strategy, get_strategy_by_name
 
 
 def run_gpu_benchmark(scene_name: str, strategy_name: str, render_cfg: RenderConfig, march_cfg: MarchConfig, *,
@@ -63,15 +63,19 @@ def run_gpu_benchmark(scene_name: str, strategy_name: str, render_cfg: RenderCon
 
 # strategy ids of the reference's fragment shader (main.glsl:64-74) -> registry keys of this engine
 GLSL_STRATEGY_KEYS = {0: "Standard", 1: "Overstep-Bisect", 2: "Relaxed", 3: "Segment", 4: "Enhanced",
-                      5: "Heuristic-Auto-Relaxed", 6: "Skipping-Spheres", 7: "RevAA"}
+                      5: "Heuristic-Auto-Relaxed", 6: "Skipping-Spheres", 7: "RevAA",
+                      8: "Safe-Relaxed", 9: "Dense-March"}      # 8, 9: shader-only (registry.SHADER_ONLY_STRATEGIES)
 # Uniforms the shader takes per run (gpu/runner.py:108-124) -> RmStrategyParams fields of the CPU-path strategies
 # that read the same constant: `omega` is RelaxedSphereTracing's constructor argument and the start value of
 # AutoRelaxedSphereTracing's omega (the shader's two relaxed marchers share the uniform, param_grid.py:21-23),
 # `beta` SlopeAutoRelaxed's, `margin` the fattening of Skipping-Spheres.
-SHADER_UNIFORMS = {"omega": ("omega", "ar_omega_init"), "beta": ("beta",), "margin": ("margin",)}
-# uniforms that exist only in the GLSL marcher bodies (segment growth, understepping): the CPU-path strategies have
-# no such constant, so only their defaults can be honoured
-_GLSL_ONLY_DEFAULTS = {"kappa": 2.0, "stepScale": 1.0}
+# `stepScale` scales the step of the shader's standard() and dense_march() (the understep oracle, groundtruth.py:59-61),
+# `minStep` is the floor of dense_march()'s stride.
+SHADER_UNIFORMS = {"omega": ("omega", "ar_omega_init"), "beta": ("beta",), "margin": ("margin",),
+                   "stepScale": ("step_scale",), "minStep": ("dense_min_step",)}
+# uniforms that exist only in the GLSL marcher bodies this engine does not build (the shader's own segment tracing):
+# only their defaults can be honoured
+_GLSL_ONLY_DEFAULTS = {"kappa": 2.0}
 
 
 class GPURunner:
@@ -80,11 +84,13 @@ class GPURunner:
 
     Deliberate differences: fp64 and the CPU camera model (the shader's pinhole ignores
     fov), the catalogue SDFs, rows top-to-bottom in both calls, `strategy_id` follows the shader's numbering
-    (GLSL_STRATEGY_KEYS; 8 = Safe-Relaxed and 9 = Dense-March exist only in GLSL and raise ValueError; pass
-    `strategy_key=` for this engine's other strategies).  `params` takes the shader's uniform names like the
-    reference seam (gpu/runner.py:120-124): omega / beta / margin reach the CPU-path strategies' constants through
-    RmStrategyParams (SHADER_UNIFORMS); RmStrategyParams field names are accepted as they are; kappa / stepScale
-    exist only in the GLSL bodies (non-default values raise NotImplementedError) and `minStep` is ignored."""
+    (GLSL_STRATEGY_KEYS; pass `strategy_key=` for this engine's other strategies).  8 = Safe-Relaxed and 9 =
+    Dense-March exist only as shader text in the reference: they run the shader's control flow on the CPU path's
+    arithmetic and are PARITY UNPINNED (nothing of the reference can check them here).  `params` takes the shader's
+    uniform names like the reference seam (gpu/runner.py:120-124): omega / beta / margin / stepScale / minStep reach
+    RmStrategyParams (SHADER_UNIFORMS; `minStep` defaults to max(hit_threshold, min_step_fraction * max_distance)
+    like the seam, gpu/runner.py:117-118); RmStrategyParams field names are accepted as they are; `kappa` belongs to
+    the shader's own segment tracing (non-default values raise NotImplementedError)."""
 
     def __init__(self, device_id: int | None = None):
         self.device_id = device_id
@@ -93,9 +99,9 @@ class GPURunner:
     def _strategy(strategy_id, strategy_key):
         if strategy_key is None:
             if strategy_id not in GLSL_STRATEGY_KEYS:
-                raise ValueError(f"strategy id {strategy_id} has no CPU-path counterpart (GLSL-only)")
+                raise ValueError(f"strategy id {strategy_id} is not one of the shader's ids (0..9)")
             strategy_key = GLSL_STRATEGY_KEYS[strategy_id]
-        st = get_strategy_by_name(strategy_key)
+        st = get_shader_strategy(strategy_key) or get_strategy_by_name(strategy_key)
         if st is None:
             raise KeyError(f"unknown strategy {strategy_key!r}")
         return st
@@ -105,8 +111,6 @@ class GPURunner:
         """Shader uniform overrides (or RmStrategyParams names) -> RmStrategyParams overrides."""
         out = {}
         for k, v in (params or {}).items():
-            if k == "minStep":
-                continue
             if k in SHADER_UNIFORMS:
                 for f in SHADER_UNIFORMS[k]:
                     out[f] = float(v)
@@ -127,9 +131,13 @@ class GPURunner:
                      render_cfg.fov_degrees, render_cfg.width, render_cfg.height)
         _native.init(self.device_id)
         lip = float(lipschitz if lipschitz is not None else 1.0) if strategy.has_lipschitz else 1.0
+        prm = dict(strategy.params, **self.strategy_params(params))
+        if strategy.key == "Dense-March" and "dense_min_step" not in prm:      # the seam's minStep (gpu/runner.py:117-118)
+            prm["dense_min_step"] = max(march_cfg.hit_threshold,
+                                        getattr(march_cfg, "min_step_fraction", 0.0) * march_cfg.max_distance)
         desc = _native.make_desc(int(scene_id), strategy.id, cam.params14(), cam.width, cam.height, 0, None,
                                  march_cfg.max_iterations, march_cfg.hit_threshold, march_cfg.max_distance, lip, True,
-                                 params=dict(strategy.params, **self.strategy_params(params)))
+                                 params=prm)
         out = _native.render(desc, want_t_raw=True, want_final_sdf=True, repeats=1 if timed else 0, want_evals=want_evals)
         return cam, out
 

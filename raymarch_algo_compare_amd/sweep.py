@@ -37,12 +37,14 @@ DEFAULT_BUDGETS = [32, 64, 128, 256, 512]                       # reference swee
 DEFAULT_EPSILONS = [1e-2, 3e-3, 1e-3, 3e-4, 1e-4, 3e-5, 1e-5]   # reference sweep.py:54
 
 # The reference's per-strategy parameter grid (param_grid.py:20-27: shader uniform -> values, first = default), by
-# registry key, for the strategies whose CPU-path arithmetic reads that constant (its Segment `kappa` and
-# Safe-Relaxed rows are GLSL-only marchers).  Uniform names are mapped by runner.SHADER_UNIFORMS.
+# registry key, for the strategies whose CPU-path arithmetic reads that constant (its Segment `kappa` row belongs to the
+# shader's own segment tracing; Safe-Relaxed is shader-only and parity unpinned -- registry.SHADER_ONLY_STRATEGIES).
+# Uniform names are mapped by runner.SHADER_UNIFORMS.
 STRATEGY_PARAM_GRID = {
     "Relaxed": {"omega": [1.2, 1.4, 1.6, 1.8]},
     "Heuristic-Auto-Relaxed": {"omega": [1.2, 1.4, 1.6, 1.8]},
     "Skipping-Spheres": {"margin": [0.02, 0.05, 0.1, 0.2]},
+    "Safe-Relaxed": {"omega": [1.2, 1.5, 1.8, 2.0]},
 }
 
 
@@ -144,7 +146,7 @@ def run_sweep(scene_names: Optional[Sequence[str]] = None, strategy_names: Optio
     for a .json path) when `out_path` is given."""
     scenes = registry.get_all_scenes() if not scene_names else [_need(registry.get_scene_by_name(n), "scene", n) for n in scene_names]
     strats = ([registry.get_strategy_by_name(k) for k in registry.list_strategies()] if not strategy_names
-              else [_need(registry.get_strategy_by_name(n), "strategy", n) for n in strategy_names])
+              else [_need(registry.get_shader_strategy(n) or registry.get_strategy_by_name(n), "strategy", n) for n in strategy_names])
     levels = build_levels(mode, budgets=budgets, epsilons=epsilons, cap=cap, hit_threshold=hit_threshold)
     collector = HipCollector(MarchConfig(), device_id=device_id)
     rows: List[Dict] = []

@@ -40,19 +40,21 @@ extern "C" {
 
 int rmh_render(int scene, int strategy, int max_iterations, double hit_threshold, double max_distance,
                double lipschitz, int full, const double* cam14, int W, int H, int row0, int rows,
-               uint8_t* hit, double* t, int32_t* iters, double* fs, const double* prm16)
+               uint8_t* hit, double* t, int32_t* iters, double* fs, const double* prm18)
 {
     MarchCfg cfg;
     cfg.hit_threshold = hit_threshold; cfg.max_distance = max_distance; cfg.lipschitz = lipschitz;
     cfg.max_iterations = max_iterations; cfg.full = full;
     cfg.prm = default_strat_params();
-    if (prm16) {   // RmStrategyParams order, the four counts as doubles
+    if (prm18) {   // RmStrategyParams order, the four counts as doubles
+        const double* prm16 = prm18;
         StratParams& p = cfg.prm;
         p.omega = prm16[0]; p.ar_omega_min = prm16[1]; p.ar_omega_max = prm16[2]; p.ar_smoothing = prm16[3];
         p.ar_growth_rate = prm16[4]; p.ar_decay_rate = prm16[5]; p.beta = prm16[6]; p.overstep_min_step = prm16[7];
         p.hybrid_stuck_step_ratio = prm16[8]; p.hybrid_min_step = prm16[9]; p.margin = prm16[10]; p.ar_omega_init = prm16[11];
         p.overstep_bisection_steps = (int32_t)prm16[12]; p.hybrid_stuck_threshold = (int32_t)prm16[13];
         p.segment_bisection_steps = (int32_t)prm16[14]; p.revaa_bisection_steps = (int32_t)prm16[15];
+        p.step_scale = prm18[16]; p.dense_min_step = prm18[17];
     }
     CameraParams cam;
     for (int i = 0; i < 14; ++i) cam.v[i] = cam14[i];

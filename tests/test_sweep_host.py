@@ -98,12 +98,11 @@ def test_param_grid_follows_the_reference():
     assert sweep.param_combos("Relaxed") == [{"omega": w} for w in (1.2, 1.4, 1.6, 1.8)]
     assert sweep.param_combos("Skipping-Spheres") == [{"margin": m} for m in (0.02, 0.05, 0.1, 0.2)]
     assert sweep.param_label({}) == "default" and sweep.param_label({"omega": 1.6}) == "omega=1.6"
-    assert GPURunner.strategy_params({"omega": 1.6, "minStep": 1.0, "kappa": 2.0, "stepScale": 1.0}) == {"omega": 1.6, "ar_omega_init": 1.6}
+    assert GPURunner.strategy_params({"omega": 1.6, "minStep": 1.0, "kappa": 2.0, "stepScale": 0.6}) == {
+        "omega": 1.6, "ar_omega_init": 1.6, "dense_min_step": 1.0, "step_scale": 0.6}
     assert GPURunner.strategy_params({"margin": 0.1, "beta": 0.5, "hybrid_stuck_threshold": 3}) == {"margin": 0.1, "beta": 0.5, "hybrid_stuck_threshold": 3}
     with pytest.raises(NotImplementedError):
         GPURunner.strategy_params({"kappa": 3.0})
-    with pytest.raises(NotImplementedError):
-        GPURunner.strategy_params({"stepScale": 0.5})
     with pytest.raises(KeyError):
         GPURunner.strategy_params({"gain": 1.0})
     assert "params" in sweep.ROW_FIELDS
