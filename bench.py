@@ -309,10 +309,11 @@ def main():
                                  "(DESIGN.md); store_path_* = the flush code alone at this frame size, store_path_8k_* = the "
                                  "same at 7680x4320"},
         }
-        # the longest ray is one dependent chain: iter_max evaluations, each as fast as a wavefront team on an idle
-        # compute unit can run it (13 us measured, tools/prof_straggler.py / DESIGN.md section 3) -- the floor of a frame
-        chain_floor_ms = float(st.iter_max) * 13e-3
-        line["chain_latency"] = {"iter_max": int(st.iter_max), "us_per_evaluation_idle_team": 13.0,
+        # the longest ray is one dependent chain: iter_max evaluations, each as fast as a wavefront team runs it once the
+        # producers have left the device (10.7 us: 464 evaluations in the 4.97 ms tail of the frame, profiles/r02_v3 /
+        # DESIGN.md section 3) -- the floor of a frame
+        chain_floor_ms = float(st.iter_max) * 10.7e-3
+        line["chain_latency"] = {"iter_max": int(st.iter_max), "us_per_evaluation_idle_team": 10.7,
                                  "floor_ms": chain_floor_ms, "frac": chain_floor_ms / kms if kms > 0 else None,
                                  "note": "frame time cannot go below the longest ray's chain; frac = floor / measured frame"}
         # what actually bounds the kernel: fp64 vector work.  530 fp64 flop per fractal iteration
