@@ -17,7 +17,7 @@ from raymarch_algo_compare_amd.camera import Camera               # noqa: E402
 
 def one_case(rng):
     sid = int(rng.choice([10, 10, 10, 14, 15, 1, 13, 12, 0, 9, 16, int(rng.integers(0, 20))]))
-    kid = int(rng.integers(0, 11))
+    kid = int(rng.integers(0, 13))                     # 11, 12: the shader-only strategies (oracle = the same shader text)
     sc = registry.SCENES[sid]
     w, h = int(rng.integers(16, 201)), int(rng.integers(16, 141))
     base = np.array(sc.camera_position or (0.0, 0.0, 5.0))
@@ -35,22 +35,27 @@ def one_case(rng):
     b1 = 0 if b0 <= 0 else int(rng.choice([0, 0, b0 + 1, b0 * 3, 100]))
     sched = dict(eval_mode=int(rng.integers(0, 3)), suspend_after=(b0, b1), resume_mode=int(rng.integers(0, 4)),
                  refill_min=int(rng.choice([0, 1, 8, 33, 64])), grid_waves=int(rng.choice([0, 0, 4, 64, 1000])),
-                 tile_order_mode=int(rng.choice([0, 0, 1, 2])), resume_grid=int(rng.choice([0, 0, 1, 7, 300])),
+                 tile_order_mode=int(rng.choice([0, 0, 1, 2, 3])), resume_grid=int(rng.choice([0, 0, 1, 7, 300])),
                  # launch structure: passes / single launch, and the single launch's knobs
                  pipeline=int(rng.choice([0, 1, 2, 2])), team_grid=int(rng.choice([0, 0, 1, 3, 40, 700])),
                  queue_first=int(rng.integers(0, 4)), team_steal=int(rng.integers(0, 3)),
                  queue_refill_min=int(rng.choice([0, 1, 16, 64])), queue_retry=int(rng.choice([0, 1, 5, 100])),
                  team_retry=int(rng.choice([0, 1, 3, 50])), age_priority=int(rng.choice([0, 0, 1, 16, 40])))
-    desc = _native.make_desc(sid, kid, cam, w, h, row0, rows, mi, thr, far, lip, True, **sched)
+    prm = None
+    if rng.random() < 0.3:                             # strategy parameters, the shader-only uniforms included
+        prm = dict(omega=float(rng.choice([1.0, 1.2, 1.5, 1.9])), step_scale=float(rng.choice([1.0, 0.6, 0.5])),
+                   dense_min_step=float(rng.choice([1e-4, 0.002, 0.02])), beta=float(rng.choice([0.3, 0.6])),
+                   overstep_bisection_steps=int(rng.choice([16, 5])), margin=float(rng.choice([0.05, 0.15])))
+    desc = _native.make_desc(sid, kid, cam, w, h, row0, rows, mi, thr, far, lip, True, params=prm, **sched)
     out = _native.render(desc, want_t_raw=True, want_final_sdf=True)
-    ref = oracle.render(sid, kid, cam, w, h, row0=row0, rows=rows, max_iterations=mi, hit_threshold=thr, max_distance=far, lipschitz=lip)
+    ref = oracle.render(sid, kid, cam, w, h, row0=row0, rows=rows, max_iterations=mi, hit_threshold=thr, max_distance=far, lipschitz=lip, params=prm)
     ok = ((out["iters"] == ref.iters).all() and (out["hit"] == ref.hit).all()
           and (out["t_raw"].view(np.uint64) == ref.t.view(np.uint64)).all()
           and (out["final_sdf"].view(np.uint64) == ref.final_sdf.view(np.uint64)).all()
           and out["stats"]["sum_iters"] == int(ref.iters.sum()) and out["stats"]["hit_count"] == int(ref.hit.sum())
           and out["stats"]["total_rays"] == ref.iters.size
           and (out["stats"]["iter_hist"] == np.bincount(ref.iters.ravel(), minlength=len(out["stats"]["iter_hist"]))).all())
-    return ok, dict(sid=sid, kid=kid, w=w, h=h, row0=row0, rows=rows, mi=mi, thr=thr, far=far, pos=pos, **sched)
+    return ok, dict(sid=sid, kid=kid, w=w, h=h, row0=row0, rows=rows, mi=mi, thr=thr, far=far, pos=pos, params=prm, **sched)
 
 
 def main():

@@ -35,7 +35,15 @@ def run(sid=10, kid=0, W=1920, H=1080, repeats=7, warmup=2, **tuning):
 
 
 exp = sys.argv[1] if len(sys.argv) > 1 else "first"
-if exp == "misc":
+if exp == "retune":
+    # after the guarded square root made the teams faster: budgets x team share, stateless and with the previous frame's costs
+    for tg in (112, 128, 160):
+        for b in ((16, 48), (16, 40), (16, 32), (24, 48), (12, 40)):
+            run(pipeline=2, suspend_after=b, team_grid=tg)
+    for b in ((32, 64), (16, 48), (24, 56), (32, 48)):
+        run(pipeline=2, suspend_after=b, tile_order_mode=1)
+        run(pipeline=2, suspend_after=b, tile_order_mode=1, team_grid=160)
+elif exp == "misc":
     # host-buffer boundary (PCIe copy back included), a band-cyclic 1/8 shard of the 8K frame, the unsharded 8K frame
     import time
     scene = registry.SCENES[10]
