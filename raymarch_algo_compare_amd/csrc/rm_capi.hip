@@ -345,10 +345,12 @@ void suspend_levels(const RmFrameDesc* d, long long rays, int mode, int* park)
     // to the teams at 48; larger frames, and Segment whose trips evaluate twice, at 32 / 64.  Every strategy gains,
     // Overstep-Bisect and Skipping-Spheres included (3.56 -> 3.08 ms, 11.3 -> 10.2 ms).
     if (mode == 2 && d->scene_id == 10 && d->march.max_iterations > 128) {
-        // (with the previous frame's tile costs the long rays start first and 32 / 64 measured best: 8.5 ms against 9.6)
+        // (with the previous frame's tile costs the long rays start first: 24 / 56 with 7/16 of the grid as teams measured
+        // 7.3-7.5 ms, 32 / 64 7.5-7.6, 16 / 48 8.5)
         const bool small = rays <= 3000000ll && d->strategy_id != 10 && d->tile_order_mode != 1;
-        if (d->suspend_after[0] == 0) park[0] = small ? 16 : 32;
-        if (d->suspend_after[1] == 0 && d->suspend_after[0] == 0) park[1] = small ? 48 : 64;
+        const bool ordered = rays <= 3000000ll && d->strategy_id != 10 && d->tile_order_mode == 1;
+        if (d->suspend_after[0] == 0) park[0] = small ? 16 : (ordered ? 24 : 32);
+        if (d->suspend_after[1] == 0 && d->suspend_after[0] == 0) park[1] = small ? 48 : (ordered ? 56 : 64);
     }
     if (park[0] == 0) park[1] = 0;
     if (park[1] > 0 && park[1] <= park[0]) park[1] = 0;
@@ -497,9 +499,25 @@ int launch_frame(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, h
         const long long team_pw = rm::kTeamShare ? rm::kSharedProducers : 0;      // producer waves of a team workgroup
         long long team_wgs = 0;
         if (teams) {
-            // default: a quarter of the resident workgroups are teams (1080p Mandelbulb: 128 of 512; 64 / 96 / 192 measured
-            // 10.0-11.5 / 10.6-11.1 / 10.4-11.5 ms against 9.6-10.0)
-            team_wgs = d->team_grid > 0 ? d->team_grid : std::max<long long>(1, resident / (rm::kTeamShare ? 2 : 4));
+            // Share of the resident workgroups that run as teams (512 resident at 2 per CU).  Measured after the guarded
+            // square root made a team's trip shorter (Mandelbulb / Standard, ms per frame by team workgroups):
+            //   960x540     128: 8.9   192: 8.4   224: 8.1            1280x720   128: 8.4   192: 8.0   224: 8.1
+            //   1920x1080   128: 9.8   160: 9.4   192: 9.4   224: 10.1  (previous frame's costs: 128: 8.5  192: 7.7  240: 7.3-7.5)
+            //   2560x1440    64: 11.7   96: 10.8  128: 11.3  192: 11.3   3840x2160  64: 19.2   96: 15.1  128: 15.2  192: 17.9
+            //   5120x2880    64: 27.6   96: 24.4  128: 26.2  192: 31.0
+            // Small frames are all tail (the chains of the long rays): more teams; large frames are fresh-pixel
+            // throughput with a short tail: more producers.
+            long long share16 = rays_total <= 1000000ll ? 7 : (rays_total <= 3000000ll ? 6 : 3);      // sixteenths of the grid
+            if (d->tile_order_mode == 1 && rays_total <= 3000000ll) share16 = 7;                      // (15/32 measured 2 % better still)
+            if (a.nframes > 1 && rays_total > 3000000ll) share16 = 4;        // sweeps: 64 x 384^2 viewpoints 29.0 ms (96: 31, 192: 34.6)
+            // Strategies whose rays end early hand few rays to the teams: Overstep-Bisect 2.95 / 3.03 / 3.32 ms and
+            // Adaptive-Hybrid 4.67 / 4.69 / 4.71 at 96 / 128 / 192 teams (with the previous frame's costs 2.81 vs 3.46
+            // and 3.79 vs 4.81 at 128 vs 224; Skipping-Spheres 6.6 vs 6.8).  The other eight gain from the larger share
+            // like Standard (Enhanced 7.26 -> 7.1, RevAA 15.1 -> 14.2; ordered: Enhanced 6.3 -> 5.6, RevAA 12.1 -> 10.4).
+            if (d->strategy_id == 6 || d->strategy_id == 9) share16 = d->tile_order_mode == 1 ? 4 : 3;
+            if (d->strategy_id == 7 && d->tile_order_mode == 1) share16 = 4;
+            if (rm::kTeamShare) share16 = 8;
+            team_wgs = d->team_grid > 0 ? d->team_grid : std::max<long long>(1, resident * share16 / 16);
             team_wgs = std::min<long long>(team_wgs, std::max<long long>(1, rm::kTeamShare ? resident : resident / 2));
         }
         const long long want_pw = d->grid_waves > 0 ? d->grid_waves : (long long)resident * rm::kPipeWaves;   // producer waves asked for

@@ -35,7 +35,29 @@ def run(sid=10, kid=0, W=1920, H=1080, repeats=7, warmup=2, **tuning):
 
 
 exp = sys.argv[1] if len(sys.argv) > 1 else "first"
-if exp == "retune":
+if exp == "retune4":
+    for kid in range(11):
+        for tg in (96, 128, 192):
+            run(kid=kid, pipeline=2, team_grid=tg)
+        for tg in (128, 224):
+            run(kid=kid, pipeline=2, team_grid=tg, tile_order_mode=1)
+elif exp == "retune3":
+    for tg in (224, 240, 256):
+        run(pipeline=2, tile_order_mode=1, team_grid=tg)
+        run(pipeline=2, tile_order_mode=1, team_grid=tg, suspend_after=(24, 56))
+    for W, H in ((2560, 1440), (3840, 2160), (5120, 2880)):
+        for tg in (32, 64, 96, 128, 192):
+            run(W=W, H=H, pipeline=2, team_grid=tg)
+    for W, H in ((960, 540), (1280, 720)):
+        for tg in (128, 192, 224):
+            run(W=W, H=H, pipeline=2, team_grid=tg)
+elif exp == "retune2":
+    for rep in range(2):
+        for tg in (128, 144, 160, 176, 192, 224):
+            run(pipeline=2, suspend_after=(16, 48), team_grid=tg)
+            run(pipeline=2, suspend_after=(24, 48), team_grid=tg)
+            run(pipeline=2, suspend_after=(32, 64), tile_order_mode=1, team_grid=tg)
+elif exp == "retune":
     # after the guarded square root made the teams faster: budgets x team share, stateless and with the previous frame's costs
     for tg in (112, 128, 160):
         for b in ((16, 48), (16, 40), (16, 32), (24, 48), (12, 40)):
