@@ -332,7 +332,9 @@ template <class Scene> struct EvalOf<Scene, true> { using type = typename Scene:
 // the configuration -- thresholds and the strategy's constructor arguments -- from the kernel arguments, i.e.
 // from scalar registers.
 template <class Scene, class Strat, int TILE_H, bool INTERLEAVE, bool BATCH>
-__global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelArgs a)
+// (two workgroups per CU at least: without the bound the register allocator may take more than 256 registers for the
+// Mandelbulb instantiations -- one wave per SIMD, the 7680x4320 frame 52 -> 69 ms when two more values became live)
+__global__ __launch_bounds__(64 * kWavesPerWG, 2) void render_kernel(const KernelArgs a)
 {
     static_assert(!INTERLEAVE || SceneIterative<Scene>::value, "INTERLEAVE needs Scene::Eval");
     constexpr int TILE_PIX = kTileW * TILE_H;
@@ -624,7 +626,7 @@ __global__ __launch_bounds__(64 * kWavesPerWG) void render_kernel(const KernelAr
 // record, so a resumed ray continues bit-for-bit where it stopped.  Results go straight to the
 // output arrays (scattered 4 + 4 + 1 byte stores of a few per cent of the pixels).
 template <class Scene, class Strat, bool INTERLEAVE, bool BATCH>
-__global__ __launch_bounds__(64 * kWavesPerWG) void resume_kernel(const KernelArgs a, const int level)
+__global__ __launch_bounds__(64 * kWavesPerWG, 2) void resume_kernel(const KernelArgs a, const int level)
 {
     static_assert(!INTERLEAVE || SceneIterative<Scene>::value, "INTERLEAVE needs Scene::Eval");
     using Entry = QEntry<Strat>;
