@@ -446,6 +446,7 @@ int launch_frame(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, h
         // A static permutation of the frame shape, computed once and kept until the shape changes: no extra launch per frame.
         long long key[12];
         frame_key(d, tile_h, key);
+        key[0] = key[1] = 0;                    // pure geometry: the same permutation for every scene and strategy
         key[10] = a.nframes; key[11] = 2;
         int rc2;
         if ((rc2 = g.corder.ensure((size_t)ntiles * 4))) return rc2;
