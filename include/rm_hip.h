@@ -117,7 +117,7 @@ typedef struct RmFrameDesc {
      *   0  the library's choice: centre-out for one-frame launches of every scene but those measured better in natural
      *      order (Pillar Forest), natural for batches of cheap scenes
      *   1  longest-first using the per-tile cost (max iterations) the previous render of the SAME frame shape left in the
-     *      library workspace -- rays that ran long last frame start first; natural order when no matching previous frame exists
+     *      library workspace -- rays that ran long last frame start first; the order of mode 0 when no matching previous frame exists
      *   2  centre-out: a static permutation of the frame shape, cached until the shape changes (the registry's cameras
      *      look at their object, so the object's grazing / fractal rays start first)
      *   3  natural (row-major tiles) */

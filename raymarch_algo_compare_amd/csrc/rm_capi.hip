@@ -442,7 +442,9 @@ int launch_frame(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, h
         a.tile_cost = (int32_t*)g.tcost.p;      // this frame's costs feed the next frame's order
         memcpy(g.cost_key, key, sizeof key);
         g.cost_valid = true;
-    } else if (order == 2) {
+        if (!a.tile_order) order = default_tile_order(d, a.nframes);    // no costs yet: the first frame takes the static order
+    }
+    if (order == 2) {
         // A static permutation of the frame shape, computed once and kept until the shape changes: no extra launch per frame.
         long long key[12];
         frame_key(d, tile_h, key);
