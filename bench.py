@@ -227,6 +227,7 @@ def main():
     # the same probe at 7680x4320 (BASELINE config 5's frame): a 1080p launch writes 18.7 MB in ~8 us, too short to
     # fill the memory pipeline; the north star's ">= 40 % of the HBM roofline on the write path" is read at this size
     store8k_gbps = None
+    tp8k = None
     if rank == 0:
         W8, H8 = 7680, 4320
         q_depth = torch.empty((H8, W8), dtype=torch.float32, device=dev)
@@ -237,6 +238,18 @@ def main():
         if L.rm_bench_store_path(W8, H8, ctypes.c_void_p(q_depth.data_ptr()), ctypes.c_void_p(q_iters.data_ptr()),
                                  ctypes.c_void_p(q_hit.data_ptr()), ctypes.byref(tm8)) == 0 and tm8.ms_median > 0:
             store8k_gbps = BYTES_PER_RAY * W8 * H8 / (tm8.ms_median * 1e-3) / 1e9
+        # the throughput regime: the same scene / strategy at 7680x4320 (BASELINE config 5's frame, unsharded), events
+        # inside the library around each of 5 frames after 2 warm-ups -- reported as `throughput_8k`, never `value`
+        if not wl["sharded"]:
+            sc8 = Camera(scene.camera_position or (0.0, 0.0, 5.0), scene.camera_target or (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 60.0, W8, H8).params14()
+            d8 = _native.make_desc(scene.id, strat_id, sc8, W8, H8, lipschitz=lip)
+            t8, s8 = _native.RmTiming(), _native.RmStats()
+            t8.warmup, t8.repeats = 2, 5
+            if L.rm_bench_device(ctypes.byref(d8), ctypes.c_void_p(q_depth.data_ptr()), ctypes.c_void_p(q_iters.data_ptr()),
+                                 ctypes.c_void_p(q_hit.data_ptr()), ctypes.byref(s8), ctypes.byref(t8)) == 0 and t8.ms_median > 0:
+                tp8k = {"value": W8 * H8 / (t8.ms_median * 1e-3) / 1e6, "unit": "Mrays/s", "ms_per_frame": t8.ms_median,
+                        "workload": f"{scene.name}/{wl['strategy']} {W8}x{H8}, one GPU, default schedule",
+                        "mean_iters_per_ray": s8.sum_iters / max(s8.total_rays, 1)}
         del q_depth, q_iters, q_hit
     # per-pass device time of a frame (events inside the library, between the passes on `stream`): a short
     # untimed loop after the measurement, so the numbers can be held against the rocprofv3 kernel stats
@@ -332,6 +345,8 @@ def main():
                 "ms_per_step": temporal / args.steps * 1e3, "grid_waves": args.temporal_grid_waves,
                 "note": "tile_order_mode=1: tiles handed out longest-first using the previous frame's per-tile "
                         "max-iteration map; identical outputs, every ray recomputed; rank-0 local figure"}
+        if tp8k is not None:
+            line["throughput_8k"] = tp8k
         if not args.no_cpu_baseline and world == 1:
             try:
                 maps = (d_depth.cpu().numpy(), d_iters.cpu().numpy(), d_hit.cpu().numpy()) if plan is None else None
