@@ -20,6 +20,11 @@
 // between two SDF evaluations is the strategy record, so every hand-over is bit-exact (same contract
 // as resume_kernel).
 //
+// DEFAULT with teams ("detach", KernelArgs.q0_detach): queue 0 is not used.  At suspend_after trips a ray is only
+// struck from its tile -- the tile is flushed without it and its slot is free again -- and marches on in its lane,
+// writing its own result, until suspend_after2 trips hand it to queue 1.  The queue-0 stage measured 4-15 x slower
+// (every producer wave polling one queue head) and is kept as a selectable, tested mode.
+//
 // Queue protocol (cdna_hip_programming.md Guideline 16, recipe R1; no order of dispatch, placement or
 // co-residency is assumed):
 //   push   lane 0 reserves slots with one agent-scope atomic add -> lanes write their entries with
