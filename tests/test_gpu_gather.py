@@ -108,5 +108,5 @@ def test_two_rank_gather_over_rccl():
     for args in (("12", "0", "1920", "1080"), ("10", "0", "640", "360"), ("0", "0", "200", "50")):
         out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                               "127.0.0.1", "--master-port", "29531", os.path.join(root, "tests", "mp_gather_check.py"), *args],
-                             capture_output=True, text=True, timeout=600, env=env, cwd=root)
+                             capture_output=True, text=True, timeout=180, env=env, cwd=root)
         assert "GATHER_OK" in out.stdout, (args, out.stdout[-2000:], out.stderr[-2000:])
