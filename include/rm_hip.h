@@ -114,13 +114,15 @@ typedef struct RmFrameDesc {
     int32_t band_offset;
     /* Tile scheduling order (results are identical in every mode; only the schedule changes -- a frame ends with its
      * longest ray, and that ray starts when the order reaches its tile).
-     *   0  the library's choice: centre-out for one-frame launches of every scene but those measured better in natural
-     *      order (Pillar Forest), natural for batches of cheap scenes
+     *   0  the library's choice: centre-out for one-frame launches of every scene but the three whose geometry runs to
+     *      the horizon (Grazing Plane, Thin Planes Stack: natural; Pillar Forest: 4), natural for batches of cheap scenes
      *   1  longest-first using the per-tile cost (max iterations) the previous render of the SAME frame shape left in the
      *      library workspace -- rays that ran long last frame start first; the order of mode 0 when no matching previous frame exists
      *   2  centre-out: a static permutation of the frame shape, cached until the shape changes (the registry's cameras
      *      look at their object, so the object's grazing / fractal rays start first)
-     *   3  natural (row-major tiles) */
+     *   3  natural (row-major tiles)
+     *   4  middle rows first (centre-out with the horizontal distance weighted 1/16): for geometry that runs to the
+     *      horizon, whose long rays lie along the horizon line (the library's choice for Pillar Forest) */
     int32_t tile_order_mode;
     /* Scenes whose SDF is a data-dependent loop (Mandelbulb, catalog.py:266-293).  0 = default
      * (library's choice, currently 2); 1 = a whole SDF evaluation per wave turn; 2 = one trip of the

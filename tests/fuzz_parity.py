@@ -35,7 +35,7 @@ def one_case(rng):
     b1 = 0 if b0 <= 0 else int(rng.choice([0, 0, b0 + 1, b0 * 3, 100]))
     sched = dict(eval_mode=int(rng.integers(0, 3)), suspend_after=(b0, b1), resume_mode=int(rng.integers(0, 4)),
                  refill_min=int(rng.choice([0, 1, 8, 33, 64])), grid_waves=int(rng.choice([0, 0, 4, 64, 1000])),
-                 tile_order_mode=int(rng.choice([0, 0, 1, 2, 3])), resume_grid=int(rng.choice([0, 0, 1, 7, 300])),
+                 tile_order_mode=int(rng.choice([0, 0, 1, 2, 3, 4])), resume_grid=int(rng.choice([0, 0, 1, 7, 300])),
                  # launch structure: passes / single launch, and the single launch's knobs
                  pipeline=int(rng.choice([0, 1, 2, 2])), team_grid=int(rng.choice([0, 0, 1, 3, 40, 700])),
                  queue_first=int(rng.integers(0, 4)), team_steal=int(rng.integers(0, 3)),
