@@ -81,6 +81,7 @@ struct State {
     int device = -1;
     hipStream_t stream = nullptr;
     hipDeviceProp_t prop;
+    bool stats_ready = false;   // the library's statistics buffer was left clean by a fused-reduce frame (launch_frame)
     Buf stats, depth, iters, hit, traw, fs, bvar, evals, in0, in1, out0, out1, out2, out3, tcost, torder, queue[rm::kQueues];
     // shape of the frame whose per-tile costs sit in `tcost` (tile_order_mode 1 needs a match)
     long long cost_key[10] = { -1 };
@@ -409,13 +410,19 @@ int launch(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, hipStre
 int launch_frame(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, hipStream_t s)
 {
     a.raw_outputs = (a.t_raw || a.final_sdf || a.evals) ? 1 : 0;
-    HIP_TRY(hipMemsetAsync(a.stats, 0, kStatsBytes, s));
-    if (d->rows == 0) return RM_OK;
     // launch structure and trip budgets first: the single launch of a scene with teams uses one-row tiles
     const long long rays_total = (long long)a.rows * a.width * a.nframes;
     int park[2];
     const int mode = pipeline_mode(d, rays_total);
     suspend_levels(d, rays_total, mode, park);
+    // One-pass frames fold their statistics in the render kernel itself (frame_reduce_by_last_workgroup) and leave the
+    // buffer zeroed where the next frame needs it: no reduce launch, and -- for the library's own buffer, which nobody
+    // else writes -- no memset either.  A caller's buffer is always cleared (its contents are not ours to trust).
+    const bool own_stats = a.stats == (unsigned long long*)g.stats.p;
+    a.fused_reduce = (park[0] == 0 && a.nframes == 1 && d->rows > 0) ? 1 : 0;
+    if (!(own_stats && g.stats_ready)) HIP_TRY(hipMemsetAsync(a.stats, 0, kStatsBytes, s));
+    if (own_stats) g.stats_ready = a.fused_reduce != 0;
+    if (d->rows == 0) return RM_OK;
     const rm::SceneLaunchers* const sc = rm::scene(d->scene_id);
     if (d->tile_rows == 1 && !(park[0] > 0 && mode == 2 && sc->has_teams))
         return fail(RM_E_BAD_ARG, "tile_rows = 1 exists for the single launch (pipeline = 2 with suspension) of scenes with a team form");
@@ -596,8 +603,10 @@ int launch_frame(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, h
             HIP_TRY(hipGetLastError());
         }
     }
-    hipLaunchKernelGGL(stats_reduce_kernel, dim3((rm::kStatsWords + 255) / 256), dim3(256), 0, s, a.stats);
-    HIP_TRY(hipGetLastError());
+    if (!a.fused_reduce) {
+        hipLaunchKernelGGL(stats_reduce_kernel, dim3((rm::kStatsWords + 255) / 256), dim3(256), 0, s, a.stats);
+        HIP_TRY(hipGetLastError());
+    }
     return RM_OK;
 }
 
@@ -819,6 +828,7 @@ void rm_shutdown(void)
     (void)hipStreamSynchronize(g.stream);
     g.corder_valid = false;
     g.cost_valid = false;
+    g.stats_ready = false;
     for (Buf* b : { &g.ccost, &g.corder, &g.ctl, &g.bstats, &g.stats, &g.depth, &g.iters, &g.hit, &g.traw, &g.fs, &g.bvar, &g.evals, &g.in0, &g.in1, &g.out0, &g.out1,
                     &g.out2, &g.out3, &g.tcost, &g.torder, &g.queue[0], &g.queue[1] })
         b->release();

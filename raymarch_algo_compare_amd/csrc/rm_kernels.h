@@ -125,6 +125,7 @@ struct KernelArgs {
                               // reference's count: its march() also evaluates for final_sdf)
     double* final_sdf;        // optional: MarchResult.final_sdf (needs cfg.full)
     int32_t raw_outputs;      // any of t_raw / evals / final_sdf is set (the kernels test this before touching the pointers)
+    int32_t fused_reduce;     // render_kernel: the last workgroup to finish folds the partial stats blocks (no reduce launch)
     long long* block_var;     // optional: (rows/4) x (width/8) variance numerators 32*sum(x^2)-sum(x)^2
     unsigned long long* stats;
     // Long-ray suspension (see resume_kernel): a ray still marching when its loop index reaches
@@ -260,6 +261,61 @@ __device__ __forceinline__ bool push_suspended(const KernelArgs& a, int q, bool 
 __device__ __forceinline__ unsigned long long* stats_part(unsigned long long* stats)
 {
     return stats + (size_t)(1 + blockIdx.x % kStatsParts) * kStatsWords;
+}
+
+// One-pass frames (no parked rays): the frame reduce without a second launch.  Every workgroup takes a ticket once its
+// own partial sums have been performed; the one that draws the last ticket folds the kStatsParts partial blocks into
+// block 0 -- what stats_reduce_kernel does for the multi-pass frames -- and leaves the buffer as a zeroed one looks to
+// the next frame: partial blocks cleared, tile counter and ticket back at 0 (block 0's totals are overwritten, never
+// added to).  The host then skips the reduce launch, and for its own statistics buffer the memset of the next frame:
+// two launches and their gaps, 11-13 us of a 0.19 ms Cube frame.
+constexpr int kWDone = 11;        // stats block 0: tickets of the workgroups that have finished (fused reduce)
+__device__ __forceinline__ void frame_reduce_by_last_workgroup(unsigned long long* stats)
+{
+    __shared__ unsigned int s_last;
+    // This thread's partial sums are device-scope atomics: performed at L2 once they have drained.  No release fence --
+    // on gfx950 it would write the L2's dirty lines back, i.e. the frame's own output tiles, once per workgroup (measured:
+    // Cube 0.19 -> 0.24 ms with __threadfence here).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = atomicAdd(&stats[kWDone], 1ull);
+        s_last = (t == (unsigned long long)gridDim.x - 1ull) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;          // workgroup-uniform
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // The histogram is empty above the frame's largest iteration count: fold iter_max first (64 loads), then only the
+    // words up to that bin -- 64 x 64 loads for a Cube frame (36 iterations) instead of 64 x 568.
+    __shared__ unsigned int s_top;
+    if (threadIdx.x < 64) {
+        unsigned long long m = 0;
+        for (int p = 1 + (int)threadIdx.x; p <= kStatsParts; p += 64) {
+            const unsigned long long v = stats[(size_t)p * kStatsWords + 3];
+            m = v > m ? v : m;
+        }
+        for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(m, off); m = o > m ? o : m; }
+        if (threadIdx.x == 0) s_top = (unsigned int)(m < (unsigned long long)(kHistBins - 1) ? m : (unsigned long long)(kHistBins - 1));
+    }
+    __syncthreads();
+    const int nwords = kStatsHead + (int)s_top + 1;
+    for (int w = threadIdx.x; w < kStatsWords; w += blockDim.x) {
+        if (w == 0 || (w >= 6 && w < 10) || (w > 10 && w < kStatsHead)) continue;     // counters live in block 0 only
+        if (w >= nwords) { stats[w] = 0ull; continue; }                                 // empty bins: block 0 may hold an older frame's
+        const bool is_max = (w == 3 || w == 4);
+        unsigned long long acc = 0;
+        // plain loads (they pipeline; atomic loads came back one at a time: +30 us): the partial blocks were only ever
+        // touched by atomics, which do not allocate in this CU's vector cache, and the acquire fence above emptied it
+#pragma unroll 16
+        for (int p = 1; p <= kStatsParts; ++p) {
+            unsigned long long* const q = stats + (size_t)p * kStatsWords + w;
+            const unsigned long long v = *q;
+            acc = is_max ? (v > acc ? v : acc) : acc + v;
+            *q = 0ull;
+        }
+        stats[w] = acc;
+    }
+    if (threadIdx.x == 0) { stats[0] = 0ull; stats[kWDone] = 0ull; }
 }
 
 // Per-wave frame totals kept in registers; one atomic each at kernel exit.
@@ -613,6 +669,7 @@ __global__ __launch_bounds__(64 * kWavesPerWG, 2) void render_kernel(const Kerne
         const unsigned int c = s_hist[b];
         if (c) atomicAdd(&part[kStatsHead + b], (unsigned long long)c);
     }
+    if (a.fused_reduce) frame_reduce_by_last_workgroup(a.stats);      // kernel-uniform
 }
 
 // ---- long-ray resume ------------------------------------------------------------------------
