@@ -184,9 +184,14 @@ int make_args(const RmFrameDesc* d, float* depth, int32_t* iters, uint8_t* hit, 
     a->tiles_y = (d->rows + th - 1) / th;
     a->tiles_per_frame = a->tiles_x * a->tiles_y;
     a->tile_h = th;
-    // refill batching: ray set-up (~250 instructions) is amortised over the idle lanes it serves; 8 idle lanes
-    // measured best or equal on every scene (Pillar Forest 1.93 -> 1.69 ms against the 24 used earlier)
-    a->refill_min = (d->refill_min > 0 && d->refill_min <= 64) ? d->refill_min : 8;
+    // refill batching: ray set-up (~250 instructions) is amortised over the idle lanes it serves.  8 idle lanes is the
+    // default (Pillar Forest 1.93 -> 1.69 ms against the 24 used earlier); the scenes whose rays are short -- set-up is a
+    // larger share of a ray -- measured better at 16 under the centre-out order (Cube 0.182 -> 0.174 ms, Cylinder
+    // 0.366 -> 0.346, Hollow Cube 0.250 -> 0.244, Box Lattice 0.377 -> 0.370, Sphere 0.353 -> 0.345, Metaballs
+    // 1.52 -> 1.49, Thin Torus 0.666 -> 0.655), the others not (Menger 0.675 -> 0.702, Pillar Forest 1.70 -> 1.74).
+    int refill_default = 8;
+    switch (d->scene_id) { case 0: case 2: case 3: case 4: case 6: case 18: case 19: refill_default = 16; break; default: break; }
+    a->refill_min = (d->refill_min > 0 && d->refill_min <= 64) ? d->refill_min : refill_default;
     a->hist_bins = rm::kHistBins;
     // one trip per turn pays where the trip count varies (Mandelbulb); the one-trip union scenes run whole evaluations
     a->interleave = d->eval_mode == 2 || (d->eval_mode == 0 && d->scene_id == 10);
