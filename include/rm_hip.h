@@ -10,7 +10,15 @@
  *
  * Ids: scene_id = index in get_all_scenes() (scenes/catalog.py:640-663), 0..19;
  *      strategy_id = index in the STRATEGIES dict (strategies/__init__.py:16-28), 0..10.
- * Threading: calls are synchronous unless stated; one in-flight call per device.
+ * Threading: every entry point may be called from any host thread; calls are serialised by one lock inside the
+ * library (one in-flight CALL per device), calls are synchronous unless stated, and frames enqueued on different streams
+ * are ordered on the device by an event (they share one workspace).  A `stream` argument must be a hipStream_t of the
+ * HIP runtime this library is bound to (rm_runtime_info).  A process can hold two copies of libamdhip64 -- this library
+ * loaded before PyTorch, whose wheel bundles its own -- and HIP dereferences whatever handle it is given, so a stream of
+ * the other copy corrupts the runtime (round 2's SIGABRT).  While two copies are mapped, only streams made by
+ * rm_stream_create are accepted (anything else: RM_E_BAD_ARG, the handle is not touched); with one copy mapped every
+ * hipStream_t of the process is that runtime's and is accepted (e.g. a torch stream when torch was imported first).
+ * Hosts without a HIP binding of their own take streams from rm_stream_create.
  */
 #ifndef RM_HIP_H
 #define RM_HIP_H
@@ -167,6 +175,15 @@ typedef struct RmFrameDesc {
     int32_t queue_retry;
     int32_t team_retry;
     int32_t age_priority;
+    /* Single launch, roles that change while the frame runs (scenes with a team form, queue_first = 0 / 3).  A frame's
+     * first milliseconds want every workgroup as a producer -- the last of its long rays is found when the tile order
+     * reaches it -- and its tail wants teams.  `late_teams` further team workgroups are put BEHIND the grid that is
+     * resident at once: the dispatcher starts one whenever a producer workgroup has left, and up to `late_teams` producer
+     * workgroups leave early (stop taking tiles, hand their rays to queue 1) when queue 1 holds `exit_backlog` (default
+     * 64) rays more than the teams have taken.  0 = none (measured: no gain at the default sizes, csrc/rm_capi.hip).
+     * Results are identical for every setting. */
+    int32_t late_teams;
+    int32_t exit_backlog;
 } RmFrameDesc;
 
 /* Frame reduce computed in-kernel (the integer part of RayMarchStats.compute, core/types.py:77-137). */
@@ -348,6 +365,39 @@ int rm_gather_frame(const RmFrameDesc* shard, const void* d_depth, const void* d
  * height x width image.  cyclic != 0: band-cyclic plan with 4-row bands; else contiguous blocks.  Asynchronous. */
 int rm_assemble_frame(int32_t world_size, int32_t height, int32_t width, int32_t rows_per_rank, int32_t cyclic,
                       int32_t elem_bytes, const void* d_gathered, void* d_full, void* stream);
+
+/* Which HIP runtime the library's calls resolve to (path of the loaded libamdhip64 and its version numbers).  Needs no
+ * device.  Stream handles passed to this library must come from THIS runtime. */
+typedef struct RmRuntimeInfo {
+    char hip_runtime_path[512];
+    int32_t hip_runtime_version;
+    int32_t hip_driver_version;
+    int32_t hip_runtimes_loaded;     /* copies of libamdhip64 mapped in this process right now (1 is the healthy case) */
+    int32_t reserved;
+    char other_runtime_path[512];    /* one of the copies that is NOT ours ("" when there is none) */
+} RmRuntimeInfo;
+int rm_runtime_info(RmRuntimeInfo* out);
+/* Streams of the library's own runtime (non-blocking streams on the bound device) for hosts that have no HIP binding:
+ * what rm_render_device / rm_gather_frame / rm_read_stats accept as `stream`.  rm_stream_synchronize(NULL) waits for the
+ * library stream; it does not hold the library lock while it waits. */
+int rm_stream_create(void** stream);
+int rm_stream_synchronize(void* stream);
+int rm_stream_destroy(void* stream);
+
+/* Test aid: fills both parked-ray queues with the 32-bit word (tag of the next single-launch frame + word_offset) -- the
+ * worst stale content a queue can hold -- and marks them as written by an unknown layout, which is what obliges the next
+ * single-launch frame to clear them (see State::qkey in csrc/rm_capi.hip).  next_generation (optional) receives that tag. */
+int rm_debug_poison_queues(uint32_t word_offset, uint32_t* next_generation);
+
+/* Development trace of single-launch frames (off by default; costs a store per ray and an atomic per ray a team
+ * finishes).  After rm_debug_set_trace(1) every single-launch frame records, for each ray a wavefront team finished, eight
+ * 32-bit words { output index, iterations, push / pop / end time in 10 ns ticks since launch, SDF evaluations at the pop
+ * and at the end, team workgroup | rays alive in the team << 16 } and, per pixel, the device-clock ticks (low 32 bits)
+ * at which its ray started and was struck from its tile (0 = never); launch_tick = the same clock at launch.
+ * tools/trace_pipeline.py turns this into the time line DESIGN.md section 3 quotes. */
+int rm_debug_set_trace(int enable);
+int rm_debug_get_trace(uint32_t* records, int64_t max_records, int64_t* nrecords, uint32_t* start_ticks,
+                       uint32_t* detach_ticks, int64_t npix, uint32_t* launch_tick);
 
 /* Store-path probe: writes the 9 B/ray outputs with the render kernel's flush code and no
  * marching, to measure the isolated HBM write bandwidth of the path. */

@@ -11,7 +11,9 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librm_hip.so")
+# RM_HIP_LIB: a development build (csrc/Makefile DEV=1 -> librm_hip_dev.so, a few kernels only) for tools/; tests and the
+# bench never set it
+LIB_PATH = os.environ.get("RM_HIP_LIB") or os.path.join(_HERE, "librm_hip.so")
 
 RM_NUM_SCENES = 20
 RM_NUM_STRATEGIES = 11
@@ -29,6 +31,8 @@ EXPORTS = [
     "rm_read_stats", "rm_bench_device", "rm_alloc_frame", "rm_free_frame", "rm_copy_frame_to_host",
     "rm_bench_store_path", "rm_render_batch", "rm_render_batch_outputs", "rm_set_pass_timing", "rm_get_pass_ms", "rm_last_queue_marks", "rm_long_ray_marks", "rm_set_queue_capacity",
     "rm_comm_unique_id", "rm_comm_init", "rm_comm_destroy", "rm_shard_rows", "rm_gather_frame", "rm_assemble_frame",
+    "rm_runtime_info", "rm_stream_create", "rm_stream_synchronize", "rm_stream_destroy", "rm_debug_poison_queues",
+    "rm_debug_set_trace", "rm_debug_get_trace",
 ]
 
 
@@ -104,7 +108,8 @@ class RmFrameDesc(ctypes.Structure):
                 ("resume_grid", ctypes.c_int32), ("resume_mode", ctypes.c_int32),
                 ("pipeline", ctypes.c_int32), ("team_grid", ctypes.c_int32), ("queue_first", ctypes.c_int32),
                 ("team_steal", ctypes.c_int32), ("queue_refill_min", ctypes.c_int32), ("queue_retry", ctypes.c_int32),
-                ("team_retry", ctypes.c_int32), ("age_priority", ctypes.c_int32)]
+                ("team_retry", ctypes.c_int32), ("age_priority", ctypes.c_int32),
+                ("late_teams", ctypes.c_int32), ("exit_backlog", ctypes.c_int32)]
 
 
 class RmOutputs(ctypes.Structure):
@@ -131,6 +136,12 @@ class RmDeviceInfo(ctypes.Structure):
                 ("device_id", ctypes.c_int32), ("compute_units", ctypes.c_int32),
                 ("clock_mhz", ctypes.c_int32), ("wavefront_size", ctypes.c_int32),
                 ("total_mem_bytes", ctypes.c_uint64)]
+
+
+class RmRuntimeInfo(ctypes.Structure):
+    _fields_ = [("hip_runtime_path", ctypes.c_char * 512), ("hip_runtime_version", ctypes.c_int32),
+                ("hip_driver_version", ctypes.c_int32), ("hip_runtimes_loaded", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("other_runtime_path", ctypes.c_char * 512)]
 
 
 _lib = None
@@ -187,6 +198,14 @@ def load() -> ctypes.CDLL:
         L.rm_shard_rows.argtypes = [ctypes.c_int32, ctypes.c_int32]
         L.rm_gather_frame.argtypes = [ctypes.POINTER(RmFrameDesc), vp, vp, vp, vp, vp, vp, vp]
         L.rm_assemble_frame.argtypes = [ctypes.c_int32] * 6 + [vp, vp, vp]
+        L.rm_runtime_info.argtypes = [ctypes.POINTER(RmRuntimeInfo)]
+        L.rm_stream_create.argtypes = [ctypes.POINTER(vp)]
+        L.rm_stream_synchronize.argtypes = [vp]
+        L.rm_stream_destroy.argtypes = [vp]
+        L.rm_debug_poison_queues.argtypes = [ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+        L.rm_debug_set_trace.argtypes = [ctypes.c_int]
+        L.rm_debug_get_trace.argtypes = [vp, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), vp, vp, ctypes.c_int64,
+                                         ctypes.POINTER(ctypes.c_uint32)]
         for name in EXPORTS:
             if name not in ("rm_shutdown", "rm_last_error", "rm_stats_device_bytes", "rm_default_strategy_params"):
                 getattr(L, name).restype = ctypes.c_int
@@ -215,6 +234,16 @@ def init(device_id: int | None = None) -> ctypes.CDLL:
     return L
 
 
+def runtime_info() -> dict:
+    """The HIP runtime librm_hip.so is bound to (no device needed): stream handles must come from this one."""
+    L = load()
+    info = RmRuntimeInfo()
+    check(L.rm_runtime_info(ctypes.byref(info)))
+    return {"hip_runtime_path": info.hip_runtime_path.decode(), "hip_runtime_version": int(info.hip_runtime_version),
+            "hip_driver_version": int(info.hip_driver_version), "hip_runtimes_loaded": int(info.hip_runtimes_loaded),
+            "other_runtime_path": info.other_runtime_path.decode()}
+
+
 def device_info() -> dict:
     L = init()
     info = RmDeviceInfo()
@@ -228,7 +257,8 @@ def make_desc(scene_id, strategy_id, cam14, width, height, row0=0, rows=None, ma
               hit_threshold=1e-4, max_distance=100.0, lipschitz=1.0, full=False, tile_rows=0, refill_min=0,
               grid_waves=0, band_rows=0, band_stride=0, band_offset=0, tile_order_mode=0, eval_mode=0,
               suspend_after=(0, 0), resume_grid=0, resume_mode=0, params: dict | None = None, pipeline=0, team_grid=0,
-              queue_first=0, team_steal=0, queue_refill_min=0, queue_retry=0, team_retry=0, age_priority=0) -> RmFrameDesc:
+              queue_first=0, team_steal=0, queue_refill_min=0, queue_retry=0, team_retry=0, age_priority=0, late_teams=0,
+              exit_backlog=0) -> RmFrameDesc:
     d = RmFrameDesc()
     d.scene_id, d.strategy_id = int(scene_id), int(strategy_id)
     d.width, d.height = int(width), int(height)
@@ -255,6 +285,7 @@ def make_desc(scene_id, strategy_id, cam14, width, height, row0=0, rows=None, ma
     d.pipeline, d.team_grid, d.queue_first, d.team_steal = int(pipeline), int(team_grid), int(queue_first), int(team_steal)
     d.queue_refill_min, d.queue_retry, d.team_retry = int(queue_refill_min), int(queue_retry), int(team_retry)
     d.age_priority = int(age_priority)
+    d.late_teams, d.exit_backlog = int(late_teams), int(exit_backlog)
     return d
 
 

@@ -5,6 +5,7 @@
 // this library: without a usable gfx950 device every entry point returns an error.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <link.h>
 #include <rccl/rccl.h>      // types and prototypes only: the library is loaded with dlopen on first use
 
 #include <algorithm>
@@ -22,13 +23,22 @@ static_assert(RM_HIST_BINS == rm::kHistBins, "histogram size mismatch between AB
 static_assert(RM_NUM_SCENES == 20 && RM_NUM_STRATEGIES == 11 && RM_NUM_STRATEGY_KERNELS == 13, "registry size");
 
 namespace rm {
+#if defined(RM_DEV_STRATEGIES)
+// development library (make DEV=1): only some scenes' translation units are linked; the others resolve to null
+#define RM_X(id, S) const SceneLaunchers* scene_launchers_##id() __attribute__((weak));
+#else
 #define RM_X(id, S) const SceneLaunchers* scene_launchers_##id();
+#endif
 RM_SCENE_LIST(RM_X)
 #undef RM_X
 static const SceneLaunchers* scene(int id)
 {
     switch (id) {
+#if defined(RM_DEV_STRATEGIES)
+#define RM_X(id, S) case id: return scene_launchers_##id ? scene_launchers_##id() : nullptr;
+#else
 #define RM_X(id, S) case id: return scene_launchers_##id();
+#endif
         RM_SCENE_LIST(RM_X)
 #undef RM_X
     }
@@ -90,6 +100,10 @@ struct State {
     bool events = false;
     Buf bstats;   // rm_render_batch: the device frame table
     Buf ctl;      // single-launch pipeline: its hot counters, one per 128-byte line
+    Buf trace, trace_start, trace_detach;   // development trace of single-launch frames (rm_debug_set_trace)
+    bool tracing = false;
+    size_t trace_pix = 0;
+    unsigned long long trace_t0 = 0;        // low bits irrelevant: the start mark of the traced frame is read back from the stats block
     Buf ccost, corder;   // single-launch pipeline: the centre-out tile order of the frame shape `corder_key`
     long long corder_key[12] = { -1 };
     bool corder_valid = false;
@@ -103,6 +117,12 @@ struct State {
     float long_marks[4] = { 0.f, 0.f, 0.f, 0.f };    // longest rays: earliest / latest push, shortest / longest stay with a team
     float last_push_ms = 0.f, last_pop_ms = 0.f;     // queue-1 marks of the last single-launch frame decoded by rm_get_pass_ms
     uint32_t generation = 0;                         // tag of the queue entries of the latest single-launch frame
+    // Who wrote each parked-ray queue last.  A single-launch consumer takes an entry for published when the word at the
+    // entry's `ready` offset equals the launch's generation tag; a frame with another entry stride (another strategy), or
+    // one that follows a multi-pass frame (entries without tags), would put those offsets on stale payload words -- old
+    // output indices, counts, halves of doubles -- that can equal a small tag.  The span a different writer may have
+    // touched is therefore cleared before a single launch uses the queue (launch_frame).
+    struct QueueKey { int stride = 0; int writer = 0; size_t used = 0; } qkey[rm::kQueues];   // writer: 1 = pass per launch, 2 = single launch, 3 = unknown
     hipEvent_t frame_ev = nullptr;                   // end of the latest frame, on `frame_stream` (frames share one workspace)
     hipStream_t frame_stream = nullptr;
     bool frame_ev_valid = false;
@@ -119,10 +139,63 @@ int check_ready()
     return RM_OK;
 }
 
+// A caller's hipStream_t must belong to the HIP runtime this library is bound to.  A process can hold two copies of
+// libamdhip64 (librm_hip.so loaded before PyTorch, whose wheel bundles its own runtime under the file name
+// libamdhip64.so: the loader does not match it with the already loaded SONAME libamdhip64.so.7); a stream made by the
+// other copy is a pointer into a foreign runtime's heap, and HIP 7.2 dereferences whatever it is handed (measured on the
+// MI355X box: hipStreamGetFlags on a pointer that is no stream faults instead of returning an error), so a handle cannot be
+// validated by asking the runtime.  What CAN be known without touching the handle: streams this library made itself
+// (rm_stream_create) are ours; and while only ONE libamdhip64 is mapped in the process, every hipStream_t there is must
+// be that runtime's.  With two copies mapped a handle we did not make is refused.
+struct HipCopies { int count; char other[256]; const void* mine; };
+int count_hip_runtimes_cb(struct dl_phdr_info* info, size_t, void* data)
+{
+    HipCopies* c = (HipCopies*)data;
+    const char* name = info->dlpi_name ? info->dlpi_name : "";
+    const char* base = strrchr(name, '/');
+    base = base ? base + 1 : name;
+    if (strncmp(base, "libamdhip64.so", 14) != 0) return 0;
+    ++c->count;
+    // is this the copy our own calls resolve to?  (its load segments contain the function's address)
+    bool ours = false;
+    for (int i = 0; i < info->dlpi_phnum; ++i) {
+        const ElfW(Phdr)& ph = info->dlpi_phdr[i];
+        if (ph.p_type != PT_LOAD) continue;
+        const char* lo = (const char*)info->dlpi_addr + ph.p_vaddr;
+        if ((const char*)c->mine >= lo && (const char*)c->mine < lo + ph.p_memsz) ours = true;
+    }
+    if (!ours) snprintf(c->other, sizeof c->other, "%s", name);
+    return 0;
+}
+HipCopies hip_runtimes_loaded()
+{
+    HipCopies c;
+    memset(&c, 0, sizeof c);
+    c.mine = reinterpret_cast<const void*>(&hipStreamCreateWithFlags);
+    dl_iterate_phdr(count_hip_runtimes_cb, &c);
+    return c;
+}
+std::vector<void*> g_own_streams, g_seen_streams;      // guarded by g_mu
+int check_stream(void* stream)
+{
+    if (!stream) return RM_OK;
+    for (void* p : g_own_streams) if (p == stream) return RM_OK;
+    for (void* p : g_seen_streams) if (p == stream) return RM_OK;
+    const HipCopies c = hip_runtimes_loaded();
+    if (c.count > 1)
+        return fail(RM_E_BAD_ARG, "stream %p was not made by rm_stream_create, and this process holds %d copies of the HIP runtime "
+                                  "(also %s): a stream of another copy cannot be used here.  Create the stream with rm_stream_create, or "
+                                  "load the other runtime's owner (e.g. import torch) BEFORE this library so both share one runtime "
+                                  "(rm_runtime_info)", stream, c.count, c.other);
+    if (g_seen_streams.size() < 4096) g_seen_streams.push_back(stream);
+    return RM_OK;
+}
+
 int check_desc(const RmFrameDesc* d)
 {
     if (!d) return fail(RM_E_BAD_ARG, "desc is NULL");
     if (d->scene_id < 0 || d->scene_id >= RM_NUM_SCENES) return fail(RM_E_BAD_SCENE, "scene_id %d out of range", d->scene_id);
+    if (!rm::scene(d->scene_id)) return fail(RM_E_BAD_SCENE, "scene %d is not built into this (development) library", d->scene_id);
     if (d->strategy_id < 0 || d->strategy_id >= RM_NUM_STRATEGY_KERNELS)
         return fail(RM_E_BAD_STRATEGY, "strategy_id %d out of range", d->strategy_id);
     if (d->width <= 0 || d->height <= 0 || d->row0 < 0 || d->rows < 0 ||
@@ -138,6 +211,7 @@ int check_desc(const RmFrameDesc* d)
     if (d->team_grid < 0 || d->queue_first < 0 || d->queue_first > 3 || d->team_steal < 0 || d->team_steal > 2 ||
         d->queue_refill_min < 0 || d->queue_refill_min > 64 || d->queue_retry < 0 || d->team_retry < 0 || d->age_priority < 0)
         return fail(RM_E_BAD_ARG, "bad single-launch tuning field");
+    if (d->exit_backlog < 0 || d->late_teams > 65536) return fail(RM_E_BAD_ARG, "bad late-team field");
     if (d->band_rows < 0 || d->band_stride < 0 || d->band_offset < 0) return fail(RM_E_BAD_ARG, "negative band parameter");
     if (d->band_rows > 0 && d->band_stride > 1) {
         const int th = d->tile_rows ? d->tile_rows : 4;
@@ -493,11 +567,22 @@ int launch_frame(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, h
         int rc;
         for (int q = 0; q < (park[1] > 0 ? 2 : 1); ++q) {
             const size_t need = (size_t)cap * (size_t)stride;
+            State::QueueKey& key = g.qkey[q];
             if (need > g.queue[q].cap) {
                 if ((rc = g.queue[q].ensure(need))) return rc;
                 // fresh memory: no word of it may look like a published entry of a later launch (QEntry.ready)
                 HIP_TRY(hipMemsetAsync(g.queue[q].p, 0, need, s));
+                key.used = 0;
             }
+            const int writer = mode == 2 ? 2 : 1;
+            if (writer == 2 && key.used > 0 && (key.writer != 2 || key.stride != stride)) {
+                // another layout wrote here: stale payload words now sit at this launch's `ready` offsets
+                HIP_TRY(hipMemsetAsync(g.queue[q].p, 0, std::min(key.used, g.queue[q].cap), s));
+                key.used = 0;
+            }
+            key.writer = writer;
+            key.stride = stride;
+            key.used = std::max(key.used, need);
             a.queue[q] = (unsigned char*)g.queue[q].p;
         }
         a.queue_cap = (int32_t)cap;
@@ -543,12 +628,28 @@ int launch_frame(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, h
             team_wgs = d->team_grid > 0 ? d->team_grid : std::max<long long>(1, resident * share16 / 16);
             team_wgs = std::min<long long>(team_wgs, std::max<long long>(1, rm::kTeamShare ? resident : resident / 2));
         }
+        // Late teams (rm_pipeline.h): by default a third of the team workgroups are resident from the start and the
+        // others are put behind the resident grid -- their places are held by producers until queue 1 fills.
+        long long late = 0;
+        const bool detach_mode = d->queue_first == 3 || (d->queue_first == 0 && teams);
+        if (teams && detach_mode && !rm::kTeamShare && d->grid_waves == 0) {
+            // measured at 1080p (Mandelbulb / Standard, trace of round 3): with 64 resident + 128 late teams the tile counter
+            // runs out at 3.8 instead of 4.6 ms and the last long ray enters queue 1 a millisecond earlier (2.5 vs 3.5 ms),
+            // but a producer workgroup only leaves when it would open its next tile (every 1-2 ms per wave in the object's
+            // tiles), the late teams arrive at 1.8-2.5 ms and the rays pushed meanwhile wait ~1.3 ms: 9.6 vs 9.8 ms.  Off by
+            // default; the demand for teams jumps from 0 to ~140 workgroups within 0.5 ms.
+            if (d->late_teams > 0) late = d->late_teams;
+        }
         const long long want_pw = d->grid_waves > 0 ? d->grid_waves : (long long)resident * rm::kPipeWaves;   // producer waves asked for
         long long pure = (std::min<long long>(want_pw, ntiles) - team_wgs * team_pw + rm::kPipeWaves - 1) / rm::kPipeWaves;
         pure = std::max<long long>(team_pw > 0 && team_wgs > 0 ? 0 : 1, std::min<long long>(pure, resident - team_wgs));
-        const long long pwgs = pure;
+        late = std::min<long long>(late, std::max<long long>(0, pure - 1));      // one producer workgroup at least stays to the end
+        const long long pwgs = pure + late;       // grid = static teams + producers + late teams
         a.team_wgs = (int32_t)team_wgs;
         a.producer_waves = (int32_t)(team_wgs * team_pw + pure * rm::kPipeWaves);
+        a.late_team_first = (int32_t)(team_wgs + pure);
+        a.early_exit_wgs = (int32_t)late;
+        a.exit_backlog = d->exit_backlog > 0 ? d->exit_backlog : 64;
         a.suspend_after2 = teams ? park[1] : 0;
         {
             int rc2;
@@ -567,6 +668,23 @@ int launch_frame(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, h
         a.team_retry = d->team_retry > 0 ? d->team_retry : 4;
         a.team_steal = d->team_steal == 0 ? 1 : (d->team_steal == 1 ? 1 : 0);
         a.max_spins = 50000;
+        a.marks = (g.pass_timing || g.tracing) ? 1 : 0;      // device-clock marks only when somebody will read them (rm_get_pass_ms)
+        if (g.tracing) {
+            constexpr size_t kTraceRecords = 1u << 20;
+            const size_t npix = (size_t)a.rows * a.width * a.nframes;
+            int rc3;
+            if ((rc3 = g.trace.ensure((8 + 8 * kTraceRecords) * 4)) || (rc3 = g.trace_start.ensure(npix * 4)) ||
+                (rc3 = g.trace_detach.ensure(npix * 4)))
+                return rc3;
+            HIP_TRY(hipMemsetAsync(g.trace.p, 0, 32, s));
+            HIP_TRY(hipMemsetAsync(g.trace_start.p, 0, npix * 4, s));
+            HIP_TRY(hipMemsetAsync(g.trace_detach.p, 0, npix * 4, s));
+            a.trace = (uint32_t*)g.trace.p;
+            a.trace_cap = (uint32_t)kTraceRecords;
+            a.trace_start = (uint32_t*)g.trace_start.p;
+            a.trace_detach = (uint32_t*)g.trace_detach.p;
+            g.trace_pix = npix;
+        }
         a.team_prio = 3;      // 0 / 1 / 3 measured alike (10.0-10.4 ms): what slows a ray next to producers is not the issue slot      // ~50 ms of polling: only reached when part of the grid is not resident
         if (a.tile_cost) HIP_TRY(hipMemsetAsync(a.tile_cost, 0, (size_t)ntiles * 4, s));   // resumed rays may report before the tile flush
         HIP_TRY(sc->pipeline(d->strategy_id, a, (int)(pwgs + team_wgs), s));
@@ -834,7 +952,10 @@ void rm_shutdown(void)
     g.corder_valid = false;
     g.cost_valid = false;
     g.stats_ready = false;
-    for (Buf* b : { &g.ccost, &g.corder, &g.ctl, &g.bstats, &g.stats, &g.depth, &g.iters, &g.hit, &g.traw, &g.fs, &g.bvar, &g.evals, &g.in0, &g.in1, &g.out0, &g.out1,
+    for (auto& k : g.qkey) k = State::QueueKey();
+    g.tracing = false;
+    g_seen_streams.clear();
+    for (Buf* b : { &g.trace, &g.trace_start, &g.trace_detach, &g.ccost, &g.corder, &g.ctl, &g.bstats, &g.stats, &g.depth, &g.iters, &g.hit, &g.traw, &g.fs, &g.bvar, &g.evals, &g.in0, &g.in1, &g.out0, &g.out1,
                     &g.out2, &g.out3, &g.tcost, &g.torder, &g.queue[0], &g.queue[1] })
         b->release();
     if (g.frame_ev_valid) (void)hipEventDestroy(g.frame_ev);
@@ -871,7 +992,7 @@ int rm_sdf_eval(int scene_id, const double* xyz, size_t n, double* out)
 {
     int rc = check_ready();
     if (rc) return rc;
-    if (scene_id < 0 || scene_id >= RM_NUM_SCENES) return fail(RM_E_BAD_SCENE, "scene_id %d out of range", scene_id);
+    if (scene_id < 0 || scene_id >= RM_NUM_SCENES || !rm::scene(scene_id)) return fail(RM_E_BAD_SCENE, "scene_id %d out of range", scene_id);
     if (n == 0) return RM_OK;
     if (!xyz || !out) return fail(RM_E_BAD_ARG, "NULL buffer");
     std::lock_guard<std::mutex> lk(g_mu);
@@ -889,7 +1010,7 @@ static int march_rays_impl(bool team, int scene_id, int strategy_id, const RmMar
 {
     int rc = check_ready();
     if (rc) return rc;
-    if (scene_id < 0 || scene_id >= RM_NUM_SCENES) return fail(RM_E_BAD_SCENE, "scene_id %d out of range", scene_id);
+    if (scene_id < 0 || scene_id >= RM_NUM_SCENES || !rm::scene(scene_id)) return fail(RM_E_BAD_SCENE, "scene_id %d out of range", scene_id);
     if (strategy_id < 0 || strategy_id >= RM_NUM_STRATEGY_KERNELS)
         return fail(RM_E_BAD_STRATEGY, "strategy_id %d out of range", strategy_id);
     if (!cfg) return fail(RM_E_BAD_ARG, "cfg is NULL");
@@ -992,6 +1113,7 @@ int rm_render_device(const RmFrameDesc* d, void* d_depth, void* d_iters, void* d
     if (!d_depth || !d_iters || !d_hit) return fail(RM_E_BAD_ARG, "device output pointers are required");
     std::lock_guard<std::mutex> lk(g_mu);     // the enqueue touches the shared workspace (queues, tile order, pass events)
     HIP_TRY(hipSetDevice(g.device));
+    if ((rc = check_stream(stream))) return rc;
     rm::KernelArgs a;
     int tile_h = 0, grid = 0;
     if ((rc = make_args(d, (float*)d_depth, (int32_t*)d_iters, (uint8_t*)d_hit, nullptr, nullptr, nullptr,
@@ -1005,6 +1127,9 @@ int rm_read_stats(const void* d_stats, void* stream, RmStats* out)
     int rc = check_ready();
     if (rc) return rc;
     if (!out) return fail(RM_E_BAD_ARG, "out is NULL");
+    std::lock_guard<std::mutex> lk(g_mu);
+    HIP_TRY(hipSetDevice(g.device));
+    if ((rc = check_stream(stream))) return rc;
     hipStream_t s = stream ? (hipStream_t)stream : g.stream;
     unsigned long long w[rm::kStatsWords];
     HIP_TRY(hipMemcpyAsync(w, d_stats ? d_stats : g.stats.p, kStatsBlockBytes, hipMemcpyDeviceToHost, s));
@@ -1103,7 +1228,10 @@ int rm_render_batch_outputs(const RmFrameDesc* shape, int32_t nframes, const dou
     HIP_TRY(hipMemcpyAsync(iters, g.iters.p, total * 4, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipMemcpyAsync(hit, g.hit.p, total, hipMemcpyDeviceToHost, g.stream));
     if (evals) HIP_TRY(hipMemcpyAsync(evals, g.evals.p, total * 4, hipMemcpyDeviceToHost, g.stream));
+    unsigned long long whead[rm::kStatsHead];
+    HIP_TRY(hipMemcpyAsync(whead, g.stats.p, sizeof whead, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
+    if (g.last_was_pipeline && (rc = check_pipeline_error(whead))) return rc;      // a wait bound hit: the maps are incomplete
     if (ms_total) HIP_TRY(hipEventElapsedTime(ms_total, g.ev[0], g.ev[1]));
     if (stats) {
         // per-frame integer reduce of the returned maps (the in-kernel block aggregates the whole batch)
@@ -1195,6 +1323,7 @@ int rm_assemble_frame(int32_t world_size, int32_t height, int32_t width, int32_t
     if (!cyclic && (long long)rows_per_rank * world_size < height) return fail(RM_E_BAD_DIMS, "the shards do not cover the frame");
     std::lock_guard<std::mutex> lk(g_mu);
     HIP_TRY(hipSetDevice(g.device));
+    if ((rc = check_stream(stream))) return rc;
     return assemble(world_size, height, width, rows_per_rank, cyclic ? 1 : 0, elem_bytes, d_gathered, d_full,
                     stream ? (hipStream_t)stream : g.stream);
 }
@@ -1209,6 +1338,7 @@ int rm_gather_frame(const RmFrameDesc* d, const void* d_depth, const void* d_ite
     std::lock_guard<std::mutex> lk(g_mu);
     if (!R.comm) return fail(RM_E_RCCL, "no communicator: call rm_comm_init() first");
     HIP_TRY(hipSetDevice(g.device));
+    if ((rc = check_stream(stream))) return rc;
     hipStream_t s = stream ? (hipStream_t)stream : g.stream;
     const int N = R.world, H = d->height, W = d->width;
     const bool cyclic = d->band_rows > 0 && d->band_stride > 1;
@@ -1283,7 +1413,10 @@ int rm_get_pass_ms(void* stream, int32_t* npasses, float* ms)
     int rc = check_ready();
     if (rc) return rc;
     if (!npasses || !ms) return fail(RM_E_BAD_ARG, "NULL output");
+    std::lock_guard<std::mutex> lk(g_mu);
+    HIP_TRY(hipSetDevice(g.device));
     if (!g.pass_timing || !g.pev_ready) return fail(RM_E_BAD_ARG, "pass timing is off (rm_set_pass_timing)");
+    if ((rc = check_stream(stream))) return rc;
     hipStream_t s = stream ? (hipStream_t)stream : g.stream;
     HIP_TRY(hipStreamSynchronize(s));
     *npasses = g.pass_count;
@@ -1317,6 +1450,7 @@ int rm_get_pass_ms(void* stream, int32_t* npasses, float* ms)
 int rm_last_queue_marks(float* last_push_ms, float* last_pop_ms)
 {
     if (!last_push_ms || !last_pop_ms) return fail(RM_E_BAD_ARG, "NULL output");
+    std::lock_guard<std::mutex> lk(g_mu);
     *last_push_ms = g.last_push_ms;
     *last_pop_ms = g.last_pop_ms;
     return RM_OK;
@@ -1325,6 +1459,7 @@ int rm_last_queue_marks(float* last_push_ms, float* last_pop_ms)
 int rm_long_ray_marks(float ms[4])
 {
     if (!ms) return fail(RM_E_BAD_ARG, "NULL output");
+    std::lock_guard<std::mutex> lk(g_mu);
     for (int i = 0; i < 4; ++i) ms[i] = g.long_marks[i];
     return RM_OK;
 }
@@ -1376,6 +1511,127 @@ int rm_copy_frame_to_host(int32_t width, int32_t rows, const void* d_depth, cons
     if (depth) HIP_TRY(hipMemcpy(depth, d_depth, n * 4, hipMemcpyDeviceToHost));
     if (iters) HIP_TRY(hipMemcpy(iters, d_iters, n * 4, hipMemcpyDeviceToHost));
     if (hit) HIP_TRY(hipMemcpy(hit, d_hit, n, hipMemcpyDeviceToHost));
+    return RM_OK;
+}
+
+int rm_debug_poison_queues(uint32_t word_offset, uint32_t* next_generation)
+{
+    int rc = check_ready();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    HIP_TRY(hipSetDevice(g.device));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    uint32_t next = g.generation + 1u;
+    if (next == 0) next = 1;
+    const uint32_t word = next + word_offset;
+    for (int q = 0; q < rm::kQueues; ++q) {
+        if (!g.queue[q].p || g.queue[q].cap == 0) continue;
+        HIP_TRY(hipMemsetD32((hipDeviceptr_t)g.queue[q].p, (int)word, g.queue[q].cap / 4));
+        g.qkey[q].writer = 3;                 // somebody else's layout: the next single launch must clear what it will poll
+        g.qkey[q].used = g.queue[q].cap;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    if (next_generation) *next_generation = next;
+    return RM_OK;
+}
+
+int rm_debug_set_trace(int enable)
+{
+    int rc = check_ready();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g.tracing = enable != 0;
+    return RM_OK;
+}
+
+int rm_debug_get_trace(uint32_t* records, int64_t max_records, int64_t* nrecords, uint32_t* start_ticks, uint32_t* detach_ticks,
+                       int64_t npix, uint32_t* launch_tick)
+{
+    int rc = check_ready();
+    if (rc) return rc;
+    if (!nrecords) return fail(RM_E_BAD_ARG, "nrecords is NULL");
+    std::lock_guard<std::mutex> lk(g_mu);
+    HIP_TRY(hipSetDevice(g.device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (!g.trace.p || !g.last_stats) return fail(RM_E_BAD_ARG, "no traced single-launch frame (rm_debug_set_trace, then render)");
+    uint32_t head[8];
+    HIP_TRY(hipMemcpy(head, g.trace.p, sizeof head, hipMemcpyDeviceToHost));
+    const int64_t n = std::min<int64_t>(head[0], 1 << 20);
+    *nrecords = n;
+    if (records && max_records > 0)
+        HIP_TRY(hipMemcpy(records, (const uint32_t*)g.trace.p + 8, (size_t)std::min<int64_t>(n, max_records) * 32, hipMemcpyDeviceToHost));
+    const size_t np = std::min<size_t>((size_t)std::max<int64_t>(npix, 0), g.trace_pix);
+    if (start_ticks && np) HIP_TRY(hipMemcpy(start_ticks, g.trace_start.p, np * 4, hipMemcpyDeviceToHost));
+    if (detach_ticks && np) HIP_TRY(hipMemcpy(detach_ticks, g.trace_detach.p, np * 4, hipMemcpyDeviceToHost));
+    if (launch_tick) {
+        unsigned long long w[rm::kStatsHead];
+        HIP_TRY(hipMemcpy(w, g.last_stats, sizeof w, hipMemcpyDeviceToHost));
+        *launch_tick = (uint32_t)(~w[rm::kWMarkStart]);
+    }
+    return RM_OK;
+}
+
+int rm_runtime_info(RmRuntimeInfo* out)
+{
+    if (!out) return fail(RM_E_BAD_ARG, "out is NULL");
+    memset(out, 0, sizeof *out);
+    // the address our own calls resolve to (a GOT entry in position-independent code), then the object that holds it
+    Dl_info info;
+    memset(&info, 0, sizeof info);
+    void* const fn = reinterpret_cast<void*>(&hipStreamCreateWithFlags);
+    if (dladdr(fn, &info) && info.dli_fname) snprintf(out->hip_runtime_path, sizeof out->hip_runtime_path, "%s", info.dli_fname);
+    const HipCopies c = hip_runtimes_loaded();
+    out->hip_runtimes_loaded = c.count;
+    snprintf(out->other_runtime_path, sizeof out->other_runtime_path, "%s", c.other);
+    int v = 0;
+    if (hipRuntimeGetVersion(&v) == hipSuccess) out->hip_runtime_version = v;
+    v = 0;
+    if (hipDriverGetVersion(&v) == hipSuccess) out->hip_driver_version = v;
+    return RM_OK;
+}
+
+int rm_stream_create(void** stream)
+{
+    int rc = check_ready();
+    if (rc) return rc;
+    if (!stream) return fail(RM_E_BAD_ARG, "stream is NULL");
+    std::lock_guard<std::mutex> lk(g_mu);
+    HIP_TRY(hipSetDevice(g.device));
+    hipStream_t s = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    g_own_streams.push_back((void*)s);
+    *stream = (void*)s;
+    return RM_OK;
+}
+
+int rm_stream_synchronize(void* stream)
+{
+    int rc = check_ready();
+    if (rc) return rc;
+    hipStream_t s;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        HIP_TRY(hipSetDevice(g.device));
+        if ((rc = check_stream(stream))) return rc;
+        s = stream ? (hipStream_t)stream : g.stream;
+    }
+    HIP_TRY(hipStreamSynchronize(s));      // outside the lock: other threads may enqueue while this one waits
+    return RM_OK;
+}
+
+int rm_stream_destroy(void* stream)
+{
+    int rc = check_ready();
+    if (rc) return rc;
+    if (!stream) return RM_OK;
+    std::lock_guard<std::mutex> lk(g_mu);
+    HIP_TRY(hipSetDevice(g.device));
+    if ((rc = check_stream(stream))) return rc;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (g.frame_ev_valid && g.frame_stream == (hipStream_t)stream) g.frame_stream = nullptr;   // its last frame has completed
+    HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    g_own_streams.erase(std::remove(g_own_streams.begin(), g_own_streams.end(), stream), g_own_streams.end());
+    g_seen_streams.erase(std::remove(g_seen_streams.begin(), g_seen_streams.end(), stream), g_seen_streams.end());
     return RM_OK;
 }
 

@@ -60,9 +60,10 @@ constexpr int kStatsBlocks = 1 + kStatsParts;
 // device-side stats block (u64 words):
 //  [0] tile counter   [1] hit_count   [2] sum_iters   [3] iter_max   [4] 0x7fffffff - iter_min
 //  [5] rays written   [6..7] entries pushed to suspended-ray queue 0 / 1   [8..9] entries handed out
-//  of queue 0 / 1   [10] SDF evaluations of the finished rays   [11..15] single-launch pipeline: progress counters
-//  and time marks (rm_pipeline.h)   [16] pipeline protocol error (0 = none)   [17..23] reserved
-//  [16 .. 16+kHistBins) histogram of iterations
+//  of queue 0 / 1   [10] SDF evaluations of the finished rays   [11] fused-reduce tickets   [12] reserved
+//  [13..15], [17..23] single-launch pipeline: time marks (rm_pipeline.h; written only when KernelArgs.marks)
+//  [16] pipeline protocol error (0 = none)
+//  [kStatsHead .. kStatsHead + kHistBins) = [24 .. 568) histogram of iterations
 // Block 0 holds the counters ([0], [6..9]) and, after stats_reduce_kernel, the totals; blocks 1..kStatsParts
 // hold the partial sums of words [1..5], [10] and of the histogram.
 // One frame of a launch: its camera and march configuration.  A launch renders `nframes` frames of the
@@ -151,6 +152,20 @@ struct KernelArgs {
     int32_t max_spins;          // polls after which a producer wave with nothing to do stops waiting for the others
     int32_t team_prio;          // s_setprio level of the team waves (0..3)
     int32_t age_prio;           // > 0: a producer wave's issue priority = (trips of its oldest ray) / age_prio, capped at 2
+    int32_t marks;              // single launch: waves leave device-clock marks in stats block 0 (rm_set_pass_timing); off in production
+    // Roles that change during the launch (rm_pipeline.h "late teams"): workgroups [late_team_first, gridDim.x) are teams
+    // the dispatcher starts when producer workgroups have left; producer workgroups [team_wgs, team_wgs + early_exit_wgs)
+    // leave (stop taking tiles, hand their detached rays to queue 1) once queue 1 holds exit_backlog rays per pending
+    // conversion more than the teams have taken.
+    int32_t late_team_first, early_exit_wgs, exit_backlog;
+    // Development trace of a single-launch frame (rm_debug_set_trace; nullptr in production): trace[0] counts the records,
+    // 8-word records from trace + 8 (one per ray a team finished: output index, iterations, push / pop / end ticks since
+    // launch, evaluations at the pop and at the end, team workgroup | live lanes << 16); per pixel the low 32 bits of
+    // the device clock when its ray started and when it was struck from its tile.
+    uint32_t* trace;
+    uint32_t trace_cap;
+    uint32_t* trace_start;
+    uint32_t* trace_detach;
 };
 
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }

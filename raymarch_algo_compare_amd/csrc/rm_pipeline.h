@@ -57,7 +57,9 @@ constexpr int kCReserved = 1;     // + q: entries reserved in queue q
 constexpr int kCTaken = 3;        // + q: entries handed out of queue q
 constexpr int kCFreshDone = 5;    // producer waves that have finished (or never had) fresh work
 constexpr int kCProdExited = 6;   // producer waves that have left their loop
-constexpr int kCtlWords = 7 * kCtlStride;
+constexpr int kCLeft = 7;         // early-exit producer workgroups that have decided to leave (late teams take their place)
+constexpr int kCLateStarted = 8;  // late team workgroups that have started
+constexpr int kCtlWords = 9 * kCtlStride;
 __device__ __forceinline__ unsigned long long* ctl(const KernelArgs& a, int k) { return a.ctl + k * kCtlStride; }
 // words of stats block 0 written once per wave (see the layout comment in rm_kernels.h)
 constexpr int kWMarkStart = 13;   // ~min s_memrealtime at kernel entry            } 100 MHz device clock,
@@ -120,8 +122,11 @@ __device__ __forceinline__ int q_claim_lane0(const KernelArgs& a, int q, int wan
 
 // Wave-uniform: lanes with `mine` wait until their entry (index base + rank) is published, then the wave
 // acquires.  The writer of an entry is between its slot reservation and its flag store: a bounded wait.
+// Returns, per lane, whether its entry may be read: false for a lane whose entry never became ready within the bound
+// (the error word is set and the lane must drop the entry -- an unpublished entry holds garbage, and its output index
+// would steer stores out of bounds).
 template <class Strat>
-__device__ __forceinline__ void q_wait_ready(const KernelArgs& a, int q, bool mine, unsigned int idx)
+__device__ __forceinline__ bool q_wait_ready(const KernelArgs& a, int q, bool mine, unsigned int idx)
 {
     const QEntry<Strat>* const e = (const QEntry<Strat>*)a.queue[q] + idx;
     bool ok = !mine;
@@ -137,6 +142,7 @@ __device__ __forceinline__ void q_wait_ready(const KernelArgs& a, int q, bool mi
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return ok;
 }
 
 // Wave-uniform push with publication: lanes with `want` append their ray to queue q.  Returns per lane
@@ -162,7 +168,7 @@ __device__ __forceinline__ bool q_push(const KernelArgs& a, int q, bool want, ui
         e.gi = gi;
         e.nev = (uint32_t)nev;
         e.ready = 0u;
-        e.pad = (uint32_t)(realtime() - ~ld_relaxed(&a.stats[kWMarkStart]));      // push time since launch (tuning marks)
+        e.pad = a.marks ? (uint32_t)(realtime() - ~ld_relaxed(&a.stats[kWMarkStart])) : 0u;      // push time since launch (tuning marks)
         e.s = s;
         unsigned long long w[NW];
         __builtin_memcpy(w, &e, sizeof e);
@@ -174,7 +180,7 @@ __device__ __forceinline__ bool q_push(const KernelArgs& a, int q, bool want, ui
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing lane's entry has left the wave
     if (ok) __hip_atomic_store((uint32_t*)(dst + 1), a.generation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (q == 1 && lane_id() == 0) atomicMax(&a.stats[kWMarkPush], realtime());
+    if (a.marks && q == 1 && lane_id() == 0) atomicMax(&a.stats[kWMarkPush], realtime());
     return ok;
 }
 
@@ -228,6 +234,7 @@ struct PipeTeamLds {
     unsigned int hist[kHistBins];
     unsigned int bar;                     // arrivals of this team's waves, monotonic
     unsigned int base, count, queue, done;
+    unsigned int ok_lo, ok_hi;            // lanes whose popped entry was published in time (part 0 polls for the team)
 };
 
 // Barrier of one team: LDS operations of a wave execute in order, so a wave's exchange writes are in LDS when
@@ -297,16 +304,24 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
     constexpr size_t kTeamOffset = kTeamShare ? sizeof(PLds) : 0;
     __shared__ __attribute__((aligned(16))) unsigned char s_role[kRoleBytes];
     __shared__ unsigned int s_hist[kHistBins];
+    __shared__ unsigned int s_leave;          // an early-exit producer workgroup has decided to leave
 
     const int lane = lane_id();
     const int wave = (int)(threadIdx.x >> 6);
     for (int b = threadIdx.x; b < kHistBins; b += blockDim.x) s_hist[b] = 0u;
+    if (threadIdx.x == 0) s_leave = 0u;
     rm_load_tables<Scene>();
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(&a.stats[kWMarkStart], ~realtime());
+    if (a.marks && threadIdx.x == 0) atomicMax(&a.stats[kWMarkStart], ~realtime());
 
     WaveAcc acc;
-    const bool team_wg = TEAMS && (int)blockIdx.x < a.team_wgs;      // workgroup-uniform
+    // Teams: workgroups [0, team_wgs) from the start of the launch, and the LATE teams [late_team_first, gridDim.x): the
+    // grid is larger than what is resident at once, the dispatcher starts a late team when an early-exit producer
+    // workgroup has left (below) -- or, at the latest, when producers finish; a team that finds nothing simply ends.
+    // A producer never waits for a team (detach mode), so no co-residency is assumed.
+    const bool late_team = TEAMS && (int)blockIdx.x >= a.late_team_first;
+    const bool team_wg = TEAMS && ((int)blockIdx.x < a.team_wgs || late_team);      // workgroup-uniform
+    if (late_team && threadIdx.x == 0) __hip_atomic_fetch_add(ctl(a, kCLateStarted), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // wave roles in a team workgroup: 0..2 = part of team 0 (3..5: team 1), -1 = leave, -2 = producer
     constexpr int kRoleAlone[8] = { 0, 1, 2, kTeamsPerWG > 1 ? 3 : -1, -1, kTeamsPerWG > 1 ? 4 : -1, kTeamsPerWG > 1 ? 5 : -1, -1 };
     constexpr int kRoleShared[8] = { 0, 1, 2, -2, -1, -2, -2, -2 };
@@ -317,7 +332,7 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
         PipeTeamLds* const T = reinterpret_cast<PipeTeamLds*>(s_role + kTeamOffset);
         for (int t = 0; t < kTeamsPerWG; ++t) {
             for (int b = threadIdx.x; b < kHistBins; b += blockDim.x) T[t].hist[b] = 0u;
-            if (threadIdx.x == 0) { T[t].bar = 0u; T[t].base = T[t].count = T[t].queue = T[t].done = 0u; }
+            if (threadIdx.x == 0) { T[t].bar = 0u; T[t].base = T[t].count = T[t].queue = T[t].done = 0u; T[t].ok_lo = T[t].ok_hi = 0u; }
         }
         __syncthreads();                     // the last workgroup-wide barrier of a team workgroup
     }
@@ -337,6 +352,7 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
         bool active = false;
         uint32_t my_gi = 0;
         uint32_t my_push = 0;                 // when this ray entered the queue (ticks since launch; tuning marks)
+        uint32_t my_pop = 0, nev_pop = 0;     // development trace: when it left the queue, evaluations it had then
         int nev = 0;
         vec3 origin = v3(0.0, 0.0, 0.0), dir = v3(0.0, 0.0, 0.0);
         MarchCfg lane_cfg = a.single.cfg;
@@ -355,40 +371,59 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
             const bool look = nidle == 64 || (nidle >= a.refill_min && since_try >= a.team_retry);
             if (look) {
                 since_try = 0;
-                if (part == 0 && lane == 0) {
-                    unsigned int base = 0;
-                    int q = 1;
-                    int cnt = q_claim_lane0(a, 1, nidle, base);
-                    if (cnt == 0 && a.team_steal) { q = 0; cnt = q_claim_lane0(a, 0, nidle, base); }
-                    unsigned int done = 0;
-                    if (cnt == 0 && nidle == 64) {
-                        // nothing anywhere: finished once no producer can push any more (one load per idle poll) and
-                        // both queues are handed out (looked at only then)
-                        const unsigned long long ex = ld_relaxed(ctl(a, kCProdExited));      // read BEFORE the queue counters
-                        if (ex >= (unsigned long long)a.producer_waves && q_available(a, 1) <= 0 && q_available(a, 0) <= 0) done = 1;
-                        const unsigned long long now = realtime();
-                        if (idle_since == 0) idle_since = now;
-                        if (!done && now - idle_since > kMaxTeamWaitTicks) { atomicMax(&a.stats[kWError], 2ull); done = 1; }
-                    } else if (cnt > 0) {
-                        idle_since = 0;
-                        if (q == 1) atomicMax(&a.stats[kWMarkPop], realtime());
+                if (part == 0) {
+                    // part 0 claims AND waits for the publication of the claimed entries: one wave decides which lanes
+                    // take a ray (a wait that runs into its bound drops the entry), the others follow its mask -- three
+                    // waves polling on their own could disagree and leave the team's lock-step
+                    unsigned int base = 0, done = 0;
+                    int q = 1, cnt = 0;
+                    if (lane == 0) {
+                        cnt = q_claim_lane0(a, 1, nidle, base);
+                        if (cnt == 0 && a.team_steal) { q = 0; cnt = q_claim_lane0(a, 0, nidle, base); }
+                        if (cnt == 0 && nidle == 64) {
+                            // nothing anywhere: finished once no producer can push any more (one load per idle poll) and
+                            // both queues are handed out (looked at only then)
+                            const unsigned long long ex = ld_relaxed(ctl(a, kCProdExited));      // read BEFORE the queue counters
+                            if (ex >= (unsigned long long)a.producer_waves && q_available(a, 1) <= 0 && q_available(a, 0) <= 0) done = 1;
+                            const unsigned long long now = realtime();
+                            if (idle_since == 0) idle_since = now;
+                            if (!done && now - idle_since > kMaxTeamWaitTicks) { atomicMax(&a.stats[kWError], 2ull); done = 1; }
+                        } else if (cnt > 0) {
+                            idle_since = 0;
+                            if (a.marks && q == 1) atomicMax(&a.stats[kWMarkPop], realtime());
+                        }
                     }
-                    L.base = base; L.count = (unsigned int)cnt; L.queue = (unsigned int)q; L.done = done;
+                    cnt = __builtin_amdgcn_readfirstlane(cnt);
+                    q = __builtin_amdgcn_readfirstlane(q);
+                    base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+                    unsigned long long okm = 0;
+                    if (cnt > 0) {
+                        const int rank = rank_in_mask(idle);
+                        const bool want = !active && rank < cnt;
+                        const bool got = q_wait_ready<Strat>(a, q, want, base + (unsigned int)rank);
+                        okm = __ballot(want && got);
+                    }
+                    if (lane == 0) {
+                        L.base = base; L.count = (unsigned int)cnt; L.queue = (unsigned int)q; L.done = done;
+                        L.ok_lo = (unsigned int)okm; L.ok_hi = (unsigned int)(okm >> 32);
+                    }
                 }
                 team_barrier(L, epoch);
                 const unsigned int base = L.base, cnt = L.count, q = L.queue, done = L.done;
+                const unsigned long long okm = ((unsigned long long)L.ok_hi << 32) | (unsigned long long)L.ok_lo;
                 team_barrier(L, epoch);       // the mailbox may be rewritten on the next look
                 if (done) break;
                 if (cnt > 0) {
+                    if (part != 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // part 0 acquired in q_wait_ready
                     const int rank = rank_in_mask(idle);
-                    const bool mine = !active && rank < (int)cnt;
-                    q_wait_ready<Strat>(a, (int)q, mine, base + (unsigned int)rank);
+                    const bool mine = ((okm >> lane) & 1ull) != 0;
                     if (mine) {
                         const Entry* const e = (const Entry*)a.queue[q] + (base + (unsigned int)rank);
                         my_gi = e->gi;
                         nev = (int)e->nev;
                         s = e->s;
                         my_push = e->pad;
+                        if (a.trace) { my_pop = (uint32_t)(realtime() - ~ld_relaxed(&a.stats[kWMarkStart])); nev_pop = (uint32_t)nev; }
                         uint32_t frame; int x, gy;
                         element_pixel(a, my_gi, frame, x, gy);
                         if constexpr (BATCH) {
@@ -419,13 +454,23 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
                 const bool fin = team_trip_lds<Scene>(ev, !ready, part, lane, L, turn, epoch);
                 if (!ready) ready = fin;
             }
+            const int live = a.trace ? __popcll(__ballot(active)) : 0;
             if (active) {
                 ++nev;
                 if (s.step(Scene::value(ev), cfg)) {
                     active = false;
                     if (part == 0) {
                         store_direct(a, my_gi, s.res, nev, acc, L.hist);
-                        if (s.res.iters >= kLongRay) {        // tuning marks of the frame's longest rays
+                        if (a.trace) {
+                            const uint32_t k = atomicAdd(&a.trace[0], 1u);
+                            if (k < a.trace_cap) {
+                                uint32_t* const r = a.trace + 8 + 8 * (size_t)k;
+                                r[0] = my_gi; r[1] = (uint32_t)s.res.iters; r[2] = my_push; r[3] = my_pop;
+                                r[4] = (uint32_t)(realtime() - ~ld_relaxed(&a.stats[kWMarkStart]));
+                                r[5] = nev_pop; r[6] = (uint32_t)nev; r[7] = (uint32_t)blockIdx.x | ((uint32_t)live << 16);
+                            }
+                        }
+                        if (a.marks && s.res.iters >= kLongRay) {        // tuning marks of the frame's longest rays
                             const unsigned long long now = realtime() - ~ld_relaxed(&a.stats[kWMarkStart]);
                             atomicMax(&a.stats[kWLongPushMax], (unsigned long long)my_push);
                             atomicMax(&a.stats[kWLongPushMin], ~(unsigned long long)my_push);
@@ -463,6 +508,9 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
     // (the tile flushes without it, the slot is free for the next tile) and it marches on in its lane as a
     // "resumed" ray.  No queue traffic at all below park1; queue 0 stays empty.
     const bool detach = a.q0_detach != 0;
+    // this workgroup may leave early to make room for a late team (wave 0 looks at the backlog, the others follow its flag)
+    const bool may_leave = TEAMS && detach && park1 > 0 && ((int)blockIdx.x - team_wgs) < a.early_exit_wgs;
+    bool leaving = false;                         // wave-uniform: no new tiles, detached rays go to queue 1 at once
 
     int slot_tile[kSlots], slot_out[kSlots];
 #pragma unroll
@@ -576,8 +624,8 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
                 if (cnt > 0) {
                     const int rank = rank_in_mask(idle);
                     const bool mine = !active && rank < cnt;
-                    q_wait_ready<Strat>(a, 0, mine, base + (unsigned int)rank);
-                    if (mine) {
+                    const bool got = q_wait_ready<Strat>(a, 0, mine, base + (unsigned int)rank);
+                    if (mine && got) {
                         const Entry* const e = (const Entry*)a.queue[0] + (base + (unsigned int)rank);
                         my_gi = e->gi;
                         nev = (int)e->nev;
@@ -608,6 +656,30 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
                 int f = -1;
 #pragma unroll
                 for (int k = kSlots - 1; k >= 0; --k) f = (slot_tile[k] < 0) ? k : f;
+                if (f >= 0 && may_leave && !first_tile) {
+                    // the decision point of an early-exit workgroup: before it would take another tile.  Leave when queue 1
+                    // holds more rays than the teams have taken -- exit_backlog for every conversion that is already under
+                    // way (left but not yet replaced by a started late team) and one more.
+                    int lv = 0;
+                    if (lane == 0) {
+                        lv = (int)__hip_atomic_load(&s_leave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (!lv && wave == 0) {
+                            const long long left = (long long)ld_relaxed(ctl(a, kCLeft)), started = (long long)ld_relaxed(ctl(a, kCLateStarted));
+                            const long long pending = left > started ? left - started : 0;
+                            if (left < (long long)a.early_exit_wgs && q_available(a, 1) >= (long long)a.exit_backlog * (1 + pending)) {
+                                __hip_atomic_fetch_add(ctl(a, kCLeft), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store(&s_leave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                lv = 1;
+                            }
+                        }
+                    }
+                    if (__builtin_amdgcn_readfirstlane(lv)) {
+                        leaving = true;
+                        more_tiles = false;
+                        dirty = true;
+                        f = -1;
+                    }
+                }
                 if (f >= 0) {
                     int tile = 0;
                     if (first_tile) {
@@ -630,7 +702,7 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
                         }
                     } else {
                         more_tiles = false;
-                        if (lane == 0) atomicMax(&a.stats[kWMarkTiles], ~realtime());
+                        if (a.marks && lane == 0) atomicMax(&a.stats[kWMarkTiles], ~realtime());
                     }
                 }
             }
@@ -670,6 +742,7 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
                         } else {
                             active = true;
                             started = true;
+                            if (a.trace_start) a.trace_start[my_gi] = (uint32_t)realtime();
                             if constexpr (INTERLEAVE) ready = Scene::begin(ev, origin + dir * s.te);   // ray.py:15-17
                         }
                     }
@@ -705,7 +778,7 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
                 fresh_reported = true;
                 if (lane == 0) {
                     add_after_drain(ctl(a, kCFreshDone), 1ull);
-                    atomicMax(&a.stats[kWMarkFresh], realtime());
+                    if (a.marks) atomicMax(&a.stats[kWMarkFresh], realtime());
                 }
             }
         }
@@ -760,7 +833,7 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
                     if (raw_out) store_raw(a, my_gi, s.res, nev);
                     acc.evals += (unsigned)nev;
                 }
-            } else if (!nopark && ((!resumed && park0 > 0 && s.i >= park0) || (resumed && park1 > 0 && s.i >= park1))) {
+            } else if (!nopark && ((!resumed && park0 > 0 && s.i >= park0) || (resumed && park1 > 0 && (s.i >= park1 || leaving)))) {
                 park = true;
             } else if constexpr (INTERLEAVE) {
                 ready = Scene::begin(ev, origin + dir * s.te);   // ray.py:15-17
@@ -772,6 +845,7 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
             bool parked = false;
             if (detach) {
                 if (p0) {                                          // struck from the tile, stays in the lane
+                    if (a.trace_detach) a.trace_detach[my_gi] = (uint32_t)realtime();
                     s_ih[my_slot][my_pix] = kSuspended;
                     fin = true;
                     resumed = true;
@@ -814,7 +888,7 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
     if (queues && lane == 0) {
         if (!fresh_reported) add_after_drain(ctl(a, kCFreshDone), 1ull);     // (a wave that never entered 2b)
         add_after_drain(ctl(a, kCProdExited), 1ull);                           // after this wave's last push
-        atomicMax(&a.stats[kWMarkProd], realtime());
+        if (a.marks) atomicMax(&a.stats[kWMarkProd], realtime());
     }
     __syncthreads();      // (in a shared team workgroup this also waits for the team waves to have left)
     // the producer waves of this workgroup flush its histogram between them

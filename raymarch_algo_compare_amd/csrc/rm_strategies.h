@@ -617,11 +617,18 @@ struct StratDenseMarch : StratBase {
 #define RM_NUM_STRATEGIES 11
 
 // X(id, functor) in registry order
+#if defined(RM_DEV_STRATEGIES)
+// development builds (make DEV=1): kernels for Standard and Enhanced only -- a scene's translation unit compiles in a
+// fraction of the time; every other strategy id is refused by the launchers.  Never shipped (the Makefile writes
+// librm_hip_dev.so, which nothing loads unless RM_HIP_LIB points at it).
+#define RM_STRATEGY_LIST(X) X(0, StratStandard) X(4, StratEnhanced)
+#else
 #define RM_STRATEGY_LIST(X)                                                                 \
     X(0, StratStandard) X(1, StratRelaxed) X(2, StratAutoRelaxed) X(3, StratSlope)          \
     X(4, StratEnhanced) X(5, StratCurvature) X(6, StratOverstepBisect) X(7, StratSkipping)  \
     X(8, StratRevAA) X(9, StratHybrid) X(10, StratSegment)                                  \
     X(11, StratSafeRelaxed) X(12, StratDenseMarch)
+#endif
 // ids [0, RM_NUM_STRATEGIES) are the CPU registry; [RM_NUM_STRATEGIES, RM_NUM_STRATEGY_KERNELS) the shader-only two
 #define RM_NUM_STRATEGY_KERNELS 13
 

@@ -136,28 +136,28 @@ def test_pass_marks_of_a_single_launch(hip):
         hip.check(L.rm_set_pass_timing(0))
 
 
-def test_frames_in_flight_on_two_streams_do_not_share_state(hip):
-    """The parked-ray queues, control block and tile-cost maps are one workspace per device: frames enqueued back to back
-    on two HIP streams (rm_render_device is asynchronous, nothing waits in between) must come out as if rendered
-    alone -- the library orders them with an event.  The boundary takes a plain hipStream_t; the streams are made by
-    the HIP runtime the library itself is bound to (symbols looked up through the library's handle: a process that
-    also holds PyTorch can contain a second copy of libamdhip64, and a stream of one copy means nothing to the other)."""
-    import ctypes
-    L = hip.load()
-    rt = L
-    vp = ctypes.c_void_p
-    rt.hipStreamCreate.argtypes = [ctypes.POINTER(vp)]
-    rt.hipStreamSynchronize.argtypes = [vp]
-    rt.hipStreamDestroy.argtypes = [vp]
+def _two_stream_cells():
     G = golden_frames("160x120")
     mb = [k for s, k in G.pairs if s == 10]
     other = [(s, k) for s, k in G.pairs if s != 10][0]
     cells = [(10, mb[0], dict(pipeline=2, suspend_after=(6, 30))), (10, mb[1], dict(pipeline=1, suspend_after=(5, 25))),
              (other[0], other[1], dict(pipeline=2, suspend_after=(4, 12))),
              (10, mb[-1], dict(pipeline=2, suspend_after=(3, 9), tile_order_mode=1)), (10, mb[0], dict(suspend_after=(-1, -1)))]
+    return G, cells
+
+
+def test_frames_in_flight_on_two_streams_do_not_share_state(hip):
+    """The parked-ray queues, control block and tile-cost maps are one workspace per device: frames enqueued back to back
+    on two HIP streams (rm_render_device is asynchronous, nothing waits in between) must come out as if rendered
+    alone -- the library orders them with an event.  Streams come from rm_stream_create, i.e. from the HIP runtime the
+    library is bound to."""
+    import ctypes
+    L = hip.load()
+    vp = ctypes.c_void_p
+    G, cells = _two_stream_cells()
     streams = [vp(), vp()]
     for st in streams:
-        assert rt.hipStreamCreate(ctypes.byref(st)) == 0
+        hip.check(L.rm_stream_create(ctypes.byref(st)))
     try:
         for rnd in range(8):
             inflight = []
@@ -172,7 +172,7 @@ def test_frames_in_flight_on_two_streams_do_not_share_state(hip):
                 hip.check(L.rm_render_device(ctypes.byref(desc), p[0], p[1], p[2], None, st))
                 inflight.append((g, p, st, (sid, kid, sched)))
             for g, p, st, what in inflight:
-                assert rt.hipStreamSynchronize(st) == 0
+                hip.check(L.rm_stream_synchronize(st))
                 w, h = g["W"], g["H"]
                 depth, iters, hit = np.empty((h, w), np.float32), np.empty((h, w), np.int32), np.empty((h, w), np.uint8)
                 hip.check(L.rm_copy_frame_to_host(w, h, p[0], p[1], p[2], depth.ctypes.data_as(vp), iters.ctypes.data_as(vp),
@@ -182,4 +182,110 @@ def test_frames_in_flight_on_two_streams_do_not_share_state(hip):
                 assert float(np.abs(depth - g["depth"]).max()) <= 1e-5, (rnd, what)
     finally:
         for st in streams:
-            rt.hipStreamDestroy(st)
+            hip.check(L.rm_stream_destroy(st))
+
+
+def test_two_host_threads_two_streams(hip):
+    """The boundary's threading claim (include/rm_hip.h "Threading"): two HOST THREADS, each with its own stream, drive the
+    library at the same time -- alloc, asynchronous render, synchronise, copy back, free -- and every frame comes out as
+    if rendered alone.  This is round 2's test that aborted on the MI355X with ONE variable changed: the streams are made
+    by the runtime the library is bound to (rm_stream_create) instead of `ctypes.CDLL("libamdhip64.so")`, which in a
+    process that imported PyTorch after librm_hip.so is a SECOND copy of the HIP runtime (DESIGN.md section 0, row
+    "b threading")."""
+    import ctypes
+    import threading
+    L = hip.load()
+    vp = ctypes.c_void_p
+    G, cells = _two_stream_cells()
+    frames = {c[:2]: G.get(c[0], c[1]) for c in cells}          # npz access stays on the main thread
+    results, errors = {}, []
+
+    def worker(tid):
+        try:
+            stream = vp()
+            hip.check(L.rm_stream_create(ctypes.byref(stream)))
+            for rep in range(6):
+                sid, kid, sched = cells[(tid * 2 + rep) % len(cells)]
+                g = frames[(sid, kid)]
+                w, h = g["W"], g["H"]
+                desc = hip.make_desc(sid, kid, g["cam"], w, h, 0, h, g["max_iterations"], g["hit_threshold"],
+                                     g["max_distance"], g["lipschitz"], False, **sched)
+                p = [vp(), vp(), vp()]
+                hip.check(L.rm_alloc_frame(w, h, *[ctypes.byref(q) for q in p]))
+                hip.check(L.rm_render_device(ctypes.byref(desc), p[0], p[1], p[2], None, stream))
+                hip.check(L.rm_stream_synchronize(stream))
+                depth, iters, hit = np.empty((h, w), np.float32), np.empty((h, w), np.int32), np.empty((h, w), np.uint8)
+                hip.check(L.rm_copy_frame_to_host(w, h, p[0], p[1], p[2], depth.ctypes.data_as(vp), iters.ctypes.data_as(vp),
+                                                  hit.ctypes.data_as(vp)))
+                hip.check(L.rm_free_frame(*p))
+                results[(tid, rep)] = (sid, kid, bool((iters == g["iters"]).all() and (hit.astype(bool) == g["hit"].astype(bool)).all()
+                                                      and float(np.abs(depth - g["depth"]).max()) <= 1e-5))
+            hip.check(L.rm_stream_destroy(stream))
+        except Exception as e:                                   # noqa: BLE001 -- reported by the main thread
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert len(results) == 12 and all(ok for _, _, ok in results.values()), results
+
+
+def test_a_stream_of_another_runtime_is_refused(hip):
+    """librm_hip.so is loaded (the `hip` fixture), THEN PyTorch: its wheel bundles a libamdhip64 of its own, so the process
+    holds two HIP runtimes -- round 2's SIGABRT ("b threading").  A handle that rm_stream_create did
+    not make is then refused with RM_E_BAD_ARG and never handed to the runtime (which would dereference it: the handle here
+    is the address of a host buffer); streams of rm_stream_create keep working."""
+    import ctypes
+    import torch                                            # noqa: F401 -- maps the second runtime
+    L = hip.load()
+    info = hip.runtime_info()
+    assert "libamdhip64" in info["hip_runtime_path"] and info["hip_runtime_version"] > 0
+    if info["hip_runtimes_loaded"] < 2:
+        pytest.skip("one HIP runtime in this process (PyTorch was imported before librm_hip.so): nothing foreign to refuse")
+    assert info["other_runtime_path"] and info["other_runtime_path"] != info["hip_runtime_path"]
+    g = golden_frames("64x48").get(0, 0)
+    desc = hip.make_desc(0, 0, g["cam"], g["W"], g["H"])
+    vp = ctypes.c_void_p
+    p = [vp(), vp(), vp()]
+    hip.check(L.rm_alloc_frame(g["W"], g["H"], *[ctypes.byref(q) for q in p]))
+    bogus = ctypes.create_string_buffer(4096)
+    own = vp()
+    hip.check(L.rm_stream_create(ctypes.byref(own)))
+    try:
+        assert L.rm_render_device(ctypes.byref(desc), p[0], p[1], p[2], None, ctypes.cast(bogus, vp)) == -6
+        assert b"copies of the HIP runtime" in L.rm_last_error()
+        assert L.rm_stream_synchronize(ctypes.cast(bogus, vp)) == -6
+        hip.check(L.rm_render_device(ctypes.byref(desc), p[0], p[1], p[2], None, own))
+        hip.check(L.rm_stream_synchronize(own))
+        hip.check(L.rm_render_device(ctypes.byref(desc), p[0], p[1], p[2], None, None))     # the library stream too
+        hip.check(L.rm_stream_synchronize(None))
+    finally:
+        hip.check(L.rm_stream_destroy(own))
+        hip.check(L.rm_free_frame(*p))
+
+
+def test_single_launch_after_another_queue_layout(hip):
+    """The `ready` word of a queue entry is compared with the launch's generation tag; the queues are reused across frames
+    with other entry strides (strategies) and by multi-pass frames, whose entries carry no tag.  Sequence: Segment single
+    launch (largest entries), Standard single launch, a multi-pass frame, single launch again -- with both queues filled
+    beforehand, and again in the middle, with words EQUAL to the tag of the next single launch (the worst stale content)."""
+    import ctypes
+    L = hip.load()
+    G = golden_frames("64x48")
+    nxt = ctypes.c_uint32(0)
+    seq = [(10, dict(pipeline=2, suspend_after=(2, 6))), (0, dict(pipeline=2, suspend_after=(2, 6))),
+           (4, dict(pipeline=1, suspend_after=(2, 6))), (0, dict(pipeline=2, suspend_after=(3, 9))),
+           (10, dict(pipeline=2, suspend_after=(1, 3), queue_first=1)), (0, dict(pipeline=2, suspend_after=(1, 3), queue_first=1))]
+    _render(hip, G.get(10, 10), 10, 10, True, pipeline=2, suspend_after=(2, 6))                 # the queues exist
+    for rnd in range(2):
+        hip.check(L.rm_debug_poison_queues(rnd, ctypes.byref(nxt)))
+        assert nxt.value != 0
+        for kid, sched in seq:
+            g = G.get(10, kid)
+            assert _check(_render(hip, g, 10, kid, True, **sched), g, 10) == (0, 0), (rnd, kid, sched)
+        hip.check(L.rm_debug_poison_queues(0, None))                                            # tag of the very next launch
+        g = G.get(10, 0)
+        assert _check(_render(hip, g, 10, 0, True, pipeline=2, suspend_after=(2, 6), team_grid=3), g, 10) == (0, 0), rnd
