@@ -48,13 +48,13 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(scene_id, strategy_id, cam14, width, height, lipschitz, gpu_maps=None):
+def cpu_baseline(scene_id, strategy_id, cam14, width, height, lipschitz, gpu_maps=None, rows_cap=1080):
     """Oracle (CPU restatement of the reference, oracle/rm_oracle.c) on a bounded sample of the
     same workload (about 10-30 s of CPU work): every host thread on the whole frame (capped at
     1080 rows) + one thread on 24 centre rows."""
     from oracle import oracle
     threads = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 64))
-    rows_mt = min(height, 1080)
+    rows_mt = min(height, rows_cap)
     r0 = (height - rows_mt) // 2
     t0 = time.perf_counter()
     fr = oracle.render(scene_id, strategy_id, cam14, width, height, row0=r0, rows=rows_mt, lipschitz=lipschitz,
@@ -84,6 +84,45 @@ def cpu_baseline(scene_id, strategy_id, cam14, width, height, lipschitz, gpu_map
         "single_thread_us_per_ray": dt1 / (rows_1t * width) * 1e6,
         "single_thread_sample": f"rows {r1}..{r1 + rows_1t - 1}, {dt1:.2f} s",
     }
+
+
+def csrc_fingerprint():
+    """sha256 over the kernel sources: a profile's counters describe ONE build of the kernels."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "raymarch_algo_compare_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip")) or name == "Makefile":
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def idle_team_pace(L, _native, scene_id, strat_id, cam14, W, H, iters_map, lip):
+    """The frame's own longest rays (>= 500 iterations) marched again by wavefront teams on an otherwise idle device
+    (rm_march_rays_team: three waves per 64 rays, nothing else resident): wall time of the call / iterations of the
+    longest ray = microseconds per evaluation of a dependent chain at its best -- the floor a frame cannot go below."""
+    import numpy as np
+    ys, xs = np.nonzero(iters_map >= 500)
+    if len(ys) == 0:
+        return None
+    ys, xs = ys[:192], xs[:192]
+    pos, fwd, right, up = (np.asarray(cam14[i:i + 3], dtype=np.float64) for i in (0, 3, 6, 9))
+    hw, hh = float(cam14[12]), float(cam14[13])
+    u = (2.0 * (xs + 0.5) / W - 1.0) * hw                      # camera.py:37-40, same IEEE operations as the kernel
+    v = (1.0 - 2.0 * (ys + 0.5) / H) * hh
+    dirs = (fwd[None, :] + right[None, :] * u[:, None]) + up[None, :] * v[:, None]
+    origins = np.repeat(pos[None, :], len(xs), axis=0)
+    best, it = None, None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        hit, t, it, fs = _native.march_rays(scene_id, strat_id, origins, dirs, lipschitz=lip, team=True)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    if not (it == iters_map[ys, xs]).all():
+        return {"error": "rm_march_rays_team disagrees with the frame on its longest rays"}
+    return {"rays": int(len(xs)), "iter_max": int(it.max()), "call_ms": best * 1e3, "us_per_evaluation": best * 1e6 / float(it.max()),
+            "note": "wall time of one rm_march_rays_team call (copies included) over the frame's own >= 500-iteration pixels / iter_max"}
 
 
 def main():
@@ -254,6 +293,7 @@ def main():
     # per-pass device time of a frame (events inside the library, between the passes on `stream`): a short
     # untimed loop after the measurement, so the numbers can be held against the rocprofv3 kernel stats
     passes = None
+    long_marks = None
     if L.rm_set_pass_timing(1) == 0:
         acc_ms, nfr = [0.0] * 4, 5
         for _ in range(nfr):
@@ -268,7 +308,16 @@ def main():
                   "-> end of the kernel (teams' tail)"] if npass.value == 4
                  else ["render_kernel (first pass)", "resume pass 1", "resume pass 2"])
         passes = {names[i]: acc_ms[i] for i in range(npass.value)}
+        lm = (ctypes.c_float * 4)()
+        if npass.value == 4 and L.rm_long_ray_marks(lm) == 0:
+            long_marks = [round(float(lm[i]), 3) for i in range(4)]
         L.rm_set_pass_timing(0)
+    pace = None
+    if rank == 0 and scene.id == 10 and not wl["sharded"]:
+        try:
+            pace = idle_team_pace(L, _native, scene.id, strat_id, cam, W, H, d_iters.cpu().numpy(), lip)
+        except Exception as e:      # a side measurement must not hide the headline
+            pace = {"error": str(e)}
     kernel_ms = [a.elapsed_time(b) for a, b in evs]
     local = torch.tensor([elapsed, float(st.total_rays), float(st.sum_iters), sum(kernel_ms) / len(kernel_ms)],
                          dtype=torch.float64, device=dev)
@@ -286,11 +335,16 @@ def main():
         value = total_rays / elapsed_max / 1e6
         rays_per_launch = float(st.total_rays)
         achieved = BYTES_PER_RAY * rays_per_launch / (kms * 1e-3) / 1e9
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_r02.json")
+        # HBM bytes per launch from the committed counter profile -- only while it describes THIS build of the kernels
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_r03.json")
         if os.path.exists(pmc_path) and args.workload == "mandelbulb-1080p":
             try:
-                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+                pmc = json.load(open(pmc_path))
+                if pmc.get("csrc_sha16") == csrc_fingerprint():
+                    traffic, traffic_src = pmc.get("hbm_bytes_per_launch"), pmc.get("source")
+                else:
+                    traffic_src = f"profiles/pmc_r03.json was collected on kernel sources {pmc.get('csrc_sha16')}, this build is {csrc_fingerprint()}: stale, not reported"
             except Exception:
                 traffic = None
         # fp64 work estimate: evaluations x ~1.76 fractal iterations x ~1100 flop
@@ -309,7 +363,7 @@ def main():
                        "rays_per_step": int(rays_step),
                        "parallelism": (f"rowshard{world}-bandcyclic4+allgather" if wl["sharded"] else f"frame-per-gpu x{world}")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms_avg": kms, "passes_ms": passes, "bytes_per_ray": BYTES_PER_RAY,
                          "store_path_GBps": store_gbps,
                          "store_path_frac": (store_gbps / HBM_PEAK_GBPS) if store_gbps else None,
@@ -322,13 +376,17 @@ def main():
                                  "(DESIGN.md); store_path_* = the flush code alone at this frame size, store_path_8k_* = the "
                                  "same at 7680x4320"},
         }
-        # the longest ray is one dependent chain: iter_max evaluations, each as fast as a wavefront team runs it once the
-        # producers have left the device (10.7 us: 464 evaluations in the 4.97 ms tail of the frame, profiles/r02_v3 /
-        # DESIGN.md section 3) -- the floor of a frame
-        chain_floor_ms = float(st.iter_max) * 10.7e-3
-        line["chain_latency"] = {"iter_max": int(st.iter_max), "us_per_evaluation_idle_team": 10.7,
-                                 "floor_ms": chain_floor_ms, "frac": chain_floor_ms / kms if kms > 0 else None,
-                                 "note": "frame time cannot go below the longest ray's chain; frac = floor / measured frame"}
+        # the longest ray is one dependent chain: iter_max evaluations, each as fast as a wavefront team runs it on an idle
+        # device -- measured here, on the frame's own longest rays (idle_team_pace)
+        if pace is not None and "us_per_evaluation" in pace:
+            chain_floor_ms = float(st.iter_max) * pace["us_per_evaluation"] * 1e-3
+            line["chain_latency"] = {"iter_max": int(st.iter_max), "idle_team": pace, "floor_ms": chain_floor_ms,
+                                     "frac": chain_floor_ms / kms if kms > 0 else None, "long_ray_marks_ms": long_marks,
+                                     "note": "frame time cannot go below the longest ray's chain; frac = floor / measured frame; "
+                                             "long_ray_marks_ms = [earliest, latest hand-over to a team, shortest, longest stay with a team] "
+                                             "of the rays that end at >= 500 iterations, device clock inside the timed kernel's twin"}
+        elif pace is not None:
+            line["chain_latency"] = pace
         # what actually bounds the kernel: fp64 vector work.  530 fp64 flop per fractal iteration
         # (SQ_INSTS_VALU_{FMA,ADD,MUL}_F64 of profiles/, one lane) x 1.76 fractal iterations per SDF
         # evaluation on this view -- an estimate, reported next to the vector-fp64 peak.
@@ -347,10 +405,11 @@ def main():
                         "max-iteration map; identical outputs, every ray recomputed; rank-0 local figure"}
         if tp8k is not None:
             line["throughput_8k"] = tp8k
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:
             try:
+                # rank 0 only, every N; with N > 1 a shorter sample (the other ranks wait at the end of the run)
                 maps = (d_depth.cpu().numpy(), d_iters.cpu().numpy(), d_hit.cpu().numpy()) if plan is None else None
-                line["cpu_baseline"] = cpu_baseline(scene.id, strat_id, cam, W, H, lip, maps)
+                line["cpu_baseline"] = cpu_baseline(scene.id, strat_id, cam, W, H, lip, maps, rows_cap=1080 if world == 1 else 360)
             except Exception as e:  # the oracle is a checker; a failure here must not hide the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port",
                                         "sample": f"unavailable: {e}"}

@@ -360,6 +360,14 @@ int32_t rm_shard_rows(int32_t height, int32_t world_size);
  * with.  Asynchronous on the stream. */
 int rm_gather_frame(const RmFrameDesc* shard, const void* d_depth, const void* d_iters, const void* d_hit,
                     void* d_full_depth, void* d_full_iters, void* d_full_hit, void* stream);
+/* The same exchange when only ONE rank needs the image (BASELINE config 5 asks for the gathered frame, not for eight
+ * copies of it): every other rank sends its shard to `root` (grouped ncclSend / ncclRecv over the direct xGMI links: the
+ * root receives 7/8 of the frame, nobody else receives anything).  Contiguous plan: the shards land straight in the image
+ * (no second pass over the frame); band-cyclic plan: in a rank-major buffer that one placement pass turns into the image.
+ * d_full_* are read on the root only (NULL elsewhere).  Asynchronous on the stream.  UNVERIFIED ON MORE THAN ONE RANK in
+ * this build environment (one GPU): covered with a communicator of one and by construction (tests/test_gpu_gather.py). */
+int rm_gather_frame_root(const RmFrameDesc* shard, const void* d_depth, const void* d_iters, const void* d_hit,
+                         void* d_full_depth, void* d_full_iters, void* d_full_hit, int32_t root, void* stream);
 /* The second half of rm_gather_frame on its own: `d_gathered` holds the shards of all ranks one after the other
  * (rank-major, rows_per_rank x width elements of elem_bytes each, as ncclAllGather leaves them); writes the
  * height x width image.  cyclic != 0: band-cyclic plan with 4-row bands; else contiguous blocks.  Asynchronous. */

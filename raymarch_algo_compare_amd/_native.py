@@ -30,7 +30,7 @@ EXPORTS = [
     "rm_sdf_eval", "rm_march_rays", "rm_march_rays_team", "rm_render", "rm_render_outputs", "rm_render_device", "rm_stats_device_bytes",
     "rm_read_stats", "rm_bench_device", "rm_alloc_frame", "rm_free_frame", "rm_copy_frame_to_host",
     "rm_bench_store_path", "rm_render_batch", "rm_render_batch_outputs", "rm_set_pass_timing", "rm_get_pass_ms", "rm_last_queue_marks", "rm_long_ray_marks", "rm_set_queue_capacity",
-    "rm_comm_unique_id", "rm_comm_init", "rm_comm_destroy", "rm_shard_rows", "rm_gather_frame", "rm_assemble_frame",
+    "rm_comm_unique_id", "rm_comm_init", "rm_comm_destroy", "rm_shard_rows", "rm_gather_frame", "rm_assemble_frame", "rm_gather_frame_root",
     "rm_runtime_info", "rm_stream_create", "rm_stream_synchronize", "rm_stream_destroy", "rm_debug_poison_queues",
     "rm_debug_set_trace", "rm_debug_get_trace",
 ]
@@ -198,6 +198,7 @@ def load() -> ctypes.CDLL:
         L.rm_shard_rows.argtypes = [ctypes.c_int32, ctypes.c_int32]
         L.rm_gather_frame.argtypes = [ctypes.POINTER(RmFrameDesc), vp, vp, vp, vp, vp, vp, vp]
         L.rm_assemble_frame.argtypes = [ctypes.c_int32] * 6 + [vp, vp, vp]
+        L.rm_gather_frame_root.argtypes = [ctypes.POINTER(RmFrameDesc), vp, vp, vp, vp, vp, vp, ctypes.c_int32, vp]
         L.rm_runtime_info.argtypes = [ctypes.POINTER(RmRuntimeInfo)]
         L.rm_stream_create.argtypes = [ctypes.POINTER(vp)]
         L.rm_stream_synchronize.argtypes = [vp]

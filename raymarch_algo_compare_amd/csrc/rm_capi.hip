@@ -459,9 +459,15 @@ void frame_key(const RmFrameDesc* d, int tile_h, long long* k)
 int default_tile_order(const RmFrameDesc* d, int nframes)
 {
     if (nframes > 1) return d->scene_id == 10 ? 2 : 3;     // Mandelbulb sweeps: centre-out within every frame
+    // Round 3 held the choice against EVERY curated viewpoint of the reference (viewpoints.py:41-123; 53 cameras at
+    // 1920x1080, Standard, profiles/r03/viewpoint_orders.jsonl): centre-out is within 5 % of the best static order for all
+    // viewpoints of 15 scenes; the plane scenes want the natural order from every camera (centre-out +15...26 %); Pillar
+    // Forest, Thin Torus (ring seen edge-on: -13 %, -8 %, -4 %) and Near Miss (the gap between the spheres: -13 %, -10 %,
+    // -4 %) the middle rows first.  Intermediate ellipses (horizontal weight 1/4, 1/2) were measured too: never the best.
+    // No single static order is within 5 % everywhere (centre-out: 17 of 53 cameras behind, natural 35, middle rows 29).
     switch (d->scene_id) {
         case 1: case 13: return 3;
-        case 12: return 4;
+        case 3: case 5: case 12: return 4;
         default: return 2;
     }
 }
@@ -800,6 +806,8 @@ struct Rccl {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -824,6 +832,8 @@ int rccl_load()
     RM_SYM(CommInitRank, ncclCommInitRank)
     RM_SYM(CommDestroy, ncclCommDestroy)
     RM_SYM(AllGather, ncclAllGather)
+    RM_SYM(Send, ncclSend)
+    RM_SYM(Recv, ncclRecv)
     RM_SYM(GroupStart, ncclGroupStart)
     RM_SYM(GroupEnd, ncclGroupEnd)
     RM_SYM(GetErrorString, ncclGetErrorString)
@@ -1328,6 +1338,29 @@ int rm_assemble_frame(int32_t world_size, int32_t height, int32_t width, int32_t
                     stream ? (hipStream_t)stream : g.stream);
 }
 
+// The plan a shard descriptor must follow on this communicator: rows every rank contributes (`per`), cyclic or not.
+static int shard_plan(const RmFrameDesc* d, int* per_out, bool* cyclic_out)
+{
+    const int N = R.world, H = d->height;
+    const bool cyclic = d->band_rows > 0 && d->band_stride > 1;
+    int per;
+    if (cyclic) {
+        if (d->band_rows != 4 || d->band_stride != N || d->band_offset != R.rank || d->row0 != 0 || H % (4 * N) != 0 || d->rows != H / N)
+            return fail(RM_E_BAD_DIMS, "band-cyclic shard does not match the communicator (4-row bands, stride = world size %d, "
+                                       "offset = rank %d, rows = height / world size)", N, R.rank);
+        per = d->rows;
+    } else {
+        per = rm_shard_rows(H, N);
+        if (N == 1) per = H;
+        const int r0 = std::min(R.rank * per, H), r1 = std::min((R.rank + 1) * per, H);
+        if (d->row0 != r0 || d->rows != r1 - r0)
+            return fail(RM_E_BAD_DIMS, "contiguous shard of rank %d must be rows [%d, %d)", R.rank, r0, r1);
+    }
+    *per_out = per;
+    *cyclic_out = cyclic;
+    return RM_OK;
+}
+
 int rm_gather_frame(const RmFrameDesc* d, const void* d_depth, const void* d_iters, const void* d_hit, void* d_full_depth,
                     void* d_full_iters, void* d_full_hit, void* stream)
 {
@@ -1341,20 +1374,9 @@ int rm_gather_frame(const RmFrameDesc* d, const void* d_depth, const void* d_ite
     if ((rc = check_stream(stream))) return rc;
     hipStream_t s = stream ? (hipStream_t)stream : g.stream;
     const int N = R.world, H = d->height, W = d->width;
-    const bool cyclic = d->band_rows > 0 && d->band_stride > 1;
-    int per;                                       // rows every rank contributes to the collective
-    if (cyclic) {
-        if (d->band_rows != 4 || d->band_stride != N || d->band_offset != R.rank || d->row0 != 0 || H % (4 * N) != 0 || d->rows != H / N)
-            return fail(RM_E_BAD_DIMS, "band-cyclic shard does not match the communicator (4-row bands, stride = world size %d, "
-                                       "offset = rank %d, rows = height / world size)", N, R.rank);
-        per = d->rows;
-    } else {
-        per = rm_shard_rows(H, N);
-        if (N == 1) per = H;
-        const int r0 = std::min(R.rank * per, H), r1 = std::min((R.rank + 1) * per, H);
-        if (d->row0 != r0 || d->rows != r1 - r0)
-            return fail(RM_E_BAD_DIMS, "contiguous shard of rank %d must be rows [%d, %d)", R.rank, r0, r1);
-    }
+    int per = 0;                                   // rows every rank contributes to the collective
+    bool cyclic = false;
+    if ((rc = shard_plan(d, &per, &cyclic))) return rc;
     const void* src[3] = { d_depth, d_iters, d_hit };
     void* dst[3] = { d_full_depth, d_full_iters, d_full_hit };
     const int eb[3] = { 4, 4, 1 };
@@ -1382,6 +1404,65 @@ int rm_gather_frame(const RmFrameDesc* d, const void* d_depth, const void* d_ite
     RCCL_TRY(R.GroupEnd());
     for (int k = 0; k < 3; ++k)
         if ((rc = assemble(N, H, W, per, cyclic ? 1 : 0, eb[k], R.gather[k].p, dst[k], s))) return rc;
+    return RM_OK;
+}
+
+int rm_gather_frame_root(const RmFrameDesc* d, const void* d_depth, const void* d_iters, const void* d_hit, void* d_full_depth,
+                         void* d_full_iters, void* d_full_hit, int32_t root, void* stream)
+{
+    int rc = check_ready();
+    if (rc) return rc;
+    if ((rc = check_desc(d))) return rc;
+    if (!d_depth || !d_iters || !d_hit) return fail(RM_E_BAD_ARG, "NULL shard buffer");
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!R.comm) return fail(RM_E_RCCL, "no communicator: call rm_comm_init() first");
+    if (root < 0 || root >= R.world) return fail(RM_E_BAD_ARG, "root %d outside the communicator of %d", root, R.world);
+    const bool is_root = R.rank == root;
+    if (is_root && (!d_full_depth || !d_full_iters || !d_full_hit)) return fail(RM_E_BAD_ARG, "the root needs the three full-frame buffers");
+    HIP_TRY(hipSetDevice(g.device));
+    if ((rc = check_stream(stream))) return rc;
+    hipStream_t s = stream ? (hipStream_t)stream : g.stream;
+    const int N = R.world, H = d->height, W = d->width;
+    int per = 0;
+    bool cyclic = false;
+    if ((rc = shard_plan(d, &per, &cyclic))) return rc;
+    const void* src[3] = { d_depth, d_iters, d_hit };
+    void* dst[3] = { d_full_depth, d_full_iters, d_full_hit };
+    const int eb[3] = { 4, 4, 1 };
+    auto rows_of = [&](int r) { return cyclic ? per : std::max(0, std::min((r + 1) * per, H) - std::min(r * per, H)); };
+    // Where rank r's rows land on the root: contiguous plan -> straight into the image (its rows are one block there: no
+    // second pass over the frame); band-cyclic plan -> slot r of a rank-major landing buffer, placed by ONE pass of
+    // assemble_rows_kernel afterwards (receiving every 4-row band into place would be H / (4 N) x 3 x (N - 1)
+    // point-to-point operations per frame: 2835 at 7680x4320 on 8 ranks).
+    if (is_root && cyclic)
+        for (int k = 0; k < 3; ++k)
+            if ((rc = R.gather[k].ensure((size_t)per * W * eb[k] * (size_t)N + 16))) return rc;
+    auto slot = [&](int k, int r) -> char* {
+        return cyclic ? (char*)R.gather[k].p + (size_t)r * per * W * eb[k] : (char*)dst[k] + (size_t)std::min(r * per, H) * W * eb[k];
+    };
+    RCCL_TRY(R.GroupStart());
+    ncclResult_t err = ncclSuccess;
+    for (int k = 0; k < 3 && err == ncclSuccess; ++k) {
+        if (!is_root) {
+            if (d->rows > 0) err = R.Send(src[k], (size_t)d->rows * W * eb[k], ncclUint8, root, R.comm, s);
+        } else {
+            for (int r = 0; r < N && err == ncclSuccess; ++r)
+                if (r != root && rows_of(r) > 0) err = R.Recv(slot(k, r), (size_t)rows_of(r) * W * eb[k], ncclUint8, r, R.comm, s);
+        }
+    }
+    if (err != ncclSuccess) {
+        (void)R.GroupEnd();
+        return fail(RM_E_RCCL, "ncclSend / ncclRecv failed: %s", R.GetErrorString(err));
+    }
+    RCCL_TRY(R.GroupEnd());
+    if (is_root) {
+        for (int k = 0; k < 3; ++k)
+            if (d->rows > 0 && slot(k, root) != (const char*)src[k])
+                HIP_TRY(hipMemcpyAsync(slot(k, root), src[k], (size_t)d->rows * W * eb[k], hipMemcpyDeviceToDevice, s));
+        if (cyclic)
+            for (int k = 0; k < 3; ++k)
+                if ((rc = assemble(N, H, W, per, 1, eb[k], R.gather[k].p, dst[k], s))) return rc;
+    }
     return RM_OK;
 }
 

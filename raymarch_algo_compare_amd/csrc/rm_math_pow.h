@@ -144,16 +144,34 @@ RM_MATH_HD double rm_pow(double x, double y)
 //   the tail of a frame, where a handful of long rays march on in nearly empty wavefronts and every instruction is
 //   on the frame's critical chain (30 dependent instructions instead of 130).  Full wavefronts go straight to pow.
 // rm_pow_half_guard is the lane-local part, shared with the host check build.
+//
+// The guard band (round 3: 1/64 ulp, was 1/32).  e_pow.c states its error budget: the exponential is within 0.509 ulp
+// AFTER the final rounding, i.e. 0.009 ulp before it, and the logarithm adds |y log x| * 1.3 * 2^-68 relative =
+// |y log x| * 1.3 * 2^-15 ulp -- below 0.001 ulp for |y log x| < 25, i.e. every squared length and every square the
+// path forms (the guards below also refuse arguments outside 2^-60 .. 2^60).  pow therefore returns the correctly
+// rounded value whenever the true value is further than 0.01 ulp from a rounding midpoint; the band asks for 1/64
+// (0.0156).  tests/test_math_exact.py: on > 10^8 spread and adversarial (near-midpoint) arguments every accepted value
+// equals libm's pow bit for bit, and the arguments on which pow and the rounded root differ all lie within 0.009 ulp
+// of a midpoint.
+// (Round 3 also built the guarded root -- and the same for x ** 2 -- into the DENSE render kernels of the algebraic
+// scenes: an evaluation whose arguments were all proven was used at once, the others waited for a masked exact block run
+// every few turns.  Bit-identical frames, but slower everywhere -- Sphere 0.35 -> 0.41 ms, Cube 0.18 -> 0.24, Pillar
+// Forest 1.7 -> 2.2: with 64 lanes x 3 % two lanes wait on every turn, so either the exact block runs nearly every turn
+// or the waiting lanes idle for a third of a 10-turn ray.  Removed; the guard stays where few lanes are live.)
+constexpr double kGuardBand = 1.0 / 64.0;
 RM_MATH_HD double rm_pow_half_guard(double x, bool* safe)
 {
     const double s = __builtin_sqrt(x);
     const double e = rm_fma(-s, s, x);
     const uint64_t sb = rm_asuint64(s);
     const double u = rm_asdouble((sb & 0x7ff0000000000000ull) - (52ull << 52));     // ulp(s); x is far inside the normal range
-    *safe = (rm_fabs(e) < 0.9375 * (s * u)) & ((sb & 0x000fffffffffffffull) != 0) & (x > 0x1p-900) & (x < 0x1p900);
+    // the true root is s + e / (2 s): at least kGuardBand ulp away from both midpoints  <=>  |e| <= (1 - 2 band) s u
+    // x = +0 (a point inside a box's slabs: length of the zero vector): pow(+0, 0.5) = +0, as the square root
+    const bool proven = (rm_fabs(e) < (1.0 - 2.0 * kGuardBand) * (s * u)) & ((sb & 0x000fffffffffffffull) != 0) & (x > 0x1p-60) & (x < 0x1p60);
+    *safe = (rm_asuint64(x) == 0ull) ? true : proven;
     return s;
 }
-constexpr int kSparseLanes = 16;      // live lanes up to which the short forms are tried (fallback odds 1 - 0.9375^n: 64 % at 16)
+constexpr int kSparseLanes = 16;      // live lanes up to which the short forms are tried (fallback odds 1 - 0.969^n: 40 % at 16)
 template <bool SPARSE>
 RM_MATH_HD double rm_pow_half(double x)
 {

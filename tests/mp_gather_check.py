@@ -45,6 +45,16 @@ def main():
                                               hit.ctypes.data_as(vp)))
         ref = _native.render(_native.make_desc(sid, kid, cam, W, H))
         ok = ok and (iters == ref["iters"]).all() and (hit == ref["hit"]).all() and (depth.view(np.uint32) == ref["depth"].view(np.uint32)).all()
+        # the gather-to-root form: only the last rank ends up with the image
+        root = world - 1
+        _native.check(L.rm_gather_frame_root(ctypes.byref(desc), shard[0], shard[1], shard[2], full[0] if rank == root else None,
+                                             full[1] if rank == root else None, full[2] if rank == root else None, root, None))
+        if rank == root:
+            _native.check(L.rm_copy_frame_to_host(W, H, full[0], full[1], full[2], depth.ctypes.data_as(vp), iters.ctypes.data_as(vp),
+                                                  hit.ctypes.data_as(vp)))
+            ok = ok and (iters == ref["iters"]).all() and (hit == ref["hit"]).all() and (depth.view(np.uint32) == ref["depth"].view(np.uint32)).all()
+        else:
+            _native.check(L.rm_stream_synchronize(None))
     _native.check(L.rm_comm_destroy())
     flags = [None] * world
     dist.all_gather_object(flags, bool(ok))

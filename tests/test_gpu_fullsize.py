@@ -261,12 +261,11 @@ def test_batch_equals_single_frames(hip):
             assert out["stats"][i]["hit_count"] == one["stats"]["hit_count"]
 
 
-def test_throughput_regime_keeps_two_waves_per_simd(hip):
-    """A guard for a register-allocation cliff ("same-box A/B"): the Mandelbulb render kernel sits a
-    few registers below the two-waves-per-SIMD limit; when it crossed it, the 7680x4320 frame went from 45-52 ms to 69 ms
-    with every parity test still green.  Loose bound: 58 ms."""
+def test_throughput_regime_frame_at_7680x4320(hip):
+    """The 7680x4320 frame runs through the plain render kernel (throughput regime) and counts every ray.  The register
+    cliff this test once guarded by wall time (two waves per SIMD need <= 256 registers) is asserted where it can be read:
+    in the code objects' metadata, tests/test_code_objects.py (CPU)."""
     sc = registry.SCENES[10]
     cam = Camera(sc.camera_position, sc.camera_target, (0.0, 1.0, 0.0), 60.0, 7680, 4320).params14()
-    out = hip.render(hip.make_desc(10, 0, cam, 7680, 4320), warmup=1, repeats=3)
+    out = hip.render(hip.make_desc(10, 0, cam, 7680, 4320), warmup=0, repeats=1)
     assert out["stats"]["total_rays"] == 7680 * 4320
-    assert out["timing"]["ms_median"] < 58.0, out["timing"]["ms_each"]

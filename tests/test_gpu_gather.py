@@ -83,6 +83,14 @@ def test_gather_entry_points_on_a_communicator_of_one(hip):
         depth, iters, hit = _to_host(hip, L, w, h, full)
         ref = hip.render(desc)
         assert (iters == ref["iters"]).all() and (hit == ref["hit"]).all() and (depth.view(np.uint32) == ref["depth"].view(np.uint32)).all()
+        # the gather-to-root form on the same communicator (one rank: the root's own shard is placed, nothing is sent)
+        hip.check(L.rm_free_frame(*full))
+        full = _alloc(hip, L, w, h)
+        hip.check(L.rm_gather_frame_root(ctypes.byref(desc), shard[0], shard[1], shard[2], full[0], full[1], full[2], 0, None))
+        d2, i2, h2 = _to_host(hip, L, w, h, full)
+        assert (i2 == ref["iters"]).all() and (h2 == ref["hit"]).all() and (d2.view(np.uint32) == ref["depth"].view(np.uint32)).all()
+        assert L.rm_gather_frame_root(ctypes.byref(desc), shard[0], shard[1], shard[2], full[0], full[1], full[2], 1, None) == -6   # no such root
+        assert L.rm_gather_frame_root(ctypes.byref(desc), shard[0], shard[1], shard[2], None, None, None, 0, None) == -6         # the root needs buffers
         bad = hip.make_desc(10, 0, cam, w, h, row0=0, rows=90)               # not this rank's shard of a 1-rank plan
         assert L.rm_gather_frame(ctypes.byref(bad), shard[0], shard[1], shard[2], full[0], full[1], full[2], None) == -3
         bad = hip.make_desc(10, 0, cam, w, h, row0=0, rows=60, band_rows=4, band_stride=3, band_offset=1)
@@ -103,10 +111,14 @@ def test_two_rank_gather_over_rccl():
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (the test box has one)")
+    import socket
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for args in (("12", "0", "1920", "1080"), ("10", "0", "640", "360"), ("0", "0", "200", "50")):
+        with socket.socket() as sk:                      # a port that is free now (no fixed port: other jobs share the host)
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
         out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                              "127.0.0.1", "--master-port", "29531", os.path.join(root, "tests", "mp_gather_check.py"), *args],
+                              "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "mp_gather_check.py"), *args],
                              capture_output=True, text=True, timeout=180, env=env, cwd=root)
         assert "GATHER_OK" in out.stdout, (args, out.stdout[-2000:], out.stderr[-2000:])

@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round-2 profiles on a GPU box (run from the repo root through gpurun): kernel stats of the bench command and of
+# Per-round profiles on a GPU box (run from the repo root through gpurun): kernel stats of the bench command and of
 # four more BASELINE cells, plus PMC counters in separate passes (MI355X_MICROARCH.md: --pmc never together with
 # tracing domains other than the kernel trace; FETCH_SIZE / WRITE_SIZE in passes of their own).
-#   tools/prof_r02.sh [out dir]
+#   tools/prof_round.sh [out dir]
 set -u
-OUT=${1:-gpurun_out/prof_r02}
+OUT=${1:-gpurun_out/prof_r03}
 mkdir -p "$OUT"
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
