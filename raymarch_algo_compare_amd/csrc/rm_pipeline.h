@@ -25,6 +25,12 @@
 // writing its own result, until suspend_after2 trips hand it to queue 1.  The queue-0 stage measured 4-15 x slower
 // (every producer wave polling one queue head) and is kept as a selectable, tested mode.
 //
+// LATE TEAMS (RmFrameDesc.late_teams, off by default): the grid may be larger than what is resident at once.  Workgroups
+// [late_team_first, gridDim.x) are teams the dispatcher starts when a producer workgroup has left; producer workgroups
+// [team_wgs, team_wgs + early_exit_wgs) leave early -- stop taking tiles, hand their struck rays to queue 1 at once -- when
+// queue 1 holds more rays than the teams have taken (one exit_backlog per conversion under way).  A producer never waits
+// for a team in detach mode, so no co-residency is assumed; a late team that finds nothing simply ends.
+//
 // Queue protocol (cdna_hip_programming.md Guideline 16, recipe R1; no order of dispatch, placement or
 // co-residency is assumed):
 //   push   lane 0 reserves slots with one agent-scope atomic add -> lanes write their entries with
