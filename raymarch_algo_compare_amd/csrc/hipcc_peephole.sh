@@ -9,7 +9,7 @@ here="$(cd "$(dirname "$0")" && pwd)"
 llvm="${ROCM_LLVM:-/opt/rocm/lib/llvm/bin}"
 hipcc="${HIPCC:-hipcc}"
 base="${out%.o}"
-"$hipcc" "$@" --cuda-device-only -S "$src" -o "$base.raw.s"
+"$hipcc" "$@" -Wno-unused-command-line-argument --cuda-device-only -S "$src" -o "$base.raw.s"
 python3 "$here/rm_peephole.py" "$base.raw.s" "$base.s"
 "$llvm/clang" -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c "$base.s" -o "$base.dev.o"
 "$llvm/lld" -flavor gnu -m elf64_amdgpu --no-undefined -shared -o "$base.hsaco" "$base.dev.o"

@@ -426,10 +426,14 @@ __global__ __launch_bounds__(64 * kWavesPerWG, 2) void render_kernel(const Kerne
 
     WaveAcc acc;
 
-    // wave-uniform scheduler state: the tiles in flight
-    int slot_tile[kSlots], slot_out[kSlots];      // tile id (-1 = free) and rays handed out but not finished
+    // wave-uniform scheduler state: the tiles in flight.  Whether a slot still has rays marching is asked of the lanes when
+    // the scheduler runs (one ballot per slot) -- not counted on every finish: the scheduler only has something to do when
+    // enough lanes are idle for a refill, and a finished tile can wait for that moment to be flushed (round 3: Sphere -2 %;
+    // generating rays 64 at a time into an LDS pool so that idle lanes only load their direction was measured as well:
+    // -1.5 % more on Sphere, nothing on Cube -- a refill already serves 40-64 lanes there -- and not kept).
+    int slot_tile[kSlots];                        // tile id (-1 = free)
 #pragma unroll
-    for (int k = 0; k < kSlots; ++k) { slot_tile[k] = -1; slot_out[k] = 0; }
+    for (int k = 0; k < kSlots; ++k) slot_tile[k] = -1;
     int cur = 0;                                  // slot currently handing out pixels
     int pool_next = TILE_PIX;                     // next unassigned pixel id of slot `cur`
     bool more_tiles = true;                       // the global tile queue may still hold work
@@ -463,7 +467,7 @@ __global__ __launch_bounds__(64 * kWavesPerWG, 2) void render_kernel(const Kerne
 #pragma unroll
         for (int k = 0; k < kSlots; ++k) {
             const bool pool_done = (k != cur) || pool_next >= TILE_PIX;
-            if (slot_tile[k] >= 0 && slot_out[k] == 0 && pool_done) {   // wave-uniform
+            if (slot_tile[k] >= 0 && pool_done && __ballot(active && my_slot == k) == 0) {   // wave-uniform
                 wave_lds_fence();     // staged results of all 64 lanes are visible
                 const TileGeom g = tile_geom<TILE_H>(a, slot_tile[k]);
                 const int gx = g.x0 + lane;
@@ -550,17 +554,13 @@ __global__ __launch_bounds__(64 * kWavesPerWG, 2) void render_kernel(const Kerne
                         dirty = true;
                         cg = tile_geom<TILE_H>(a, tile);
 #pragma unroll
-                        for (int k = 0; k < kSlots; ++k) {
-                            slot_tile[k] = (k == f) ? tile : slot_tile[k];
-                            slot_out[k] = (k == f) ? 0 : slot_out[k];
-                        }
+                        for (int k = 0; k < kSlots; ++k) slot_tile[k] = (k == f) ? tile : slot_tile[k];
                     } else {
                         more_tiles = false;   // every wave gets here: the grid always drains
                     }
                 }
             }
             if (pool_next < TILE_PIX) {
-                bool started = false;
                 if (!active) {
                     // block-major pixel order: 32 consecutive ids form one 8x4 block, so a fresh
                     // wave starts on a compact 16x4 patch (coherent rays, similar trip counts)
@@ -588,16 +588,12 @@ __global__ __launch_bounds__(64 * kWavesPerWG, 2) void render_kernel(const Kerne
                             acc.evals += (unsigned)nev;
                         } else {
                             active = true;
-                            started = true;
                             if constexpr (INTERLEAVE) {
                                 ready = Scene::begin(ev, origin + dir * s.te);   // ray.py:15-17
                             }
                         }
                     }
                 }
-                const int nstarted = __popcll(__ballot(started));
-#pragma unroll
-                for (int k = 0; k < kSlots; ++k) slot_out[k] += (k == cur) ? nstarted : 0;
                 pool_next += nidle;
                 dirty = true;
             }
@@ -664,9 +660,9 @@ __global__ __launch_bounds__(64 * kWavesPerWG, 2) void render_kernel(const Kerne
             }
         }
         if (__any(fin)) {
-#pragma unroll
-            for (int k = 0; k < kSlots; ++k) slot_out[k] -= __popcll(__ballot(fin && my_slot == k));
-            dirty = true;
+            // the scheduler has work only when a refill is due (idle lanes >= refill_min; finished tiles are flushed then)
+            const int nidle_now = 64 - __popcll(__ballot(active));
+            dirty = dirty || nidle_now >= a.refill_min;
         }
         }
         // with age priority on, the scheduler also runs every 16 turns so an ageing ray is noticed without a finish
