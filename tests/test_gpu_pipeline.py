@@ -290,3 +290,36 @@ def test_single_launch_after_another_queue_layout(hip):
         hip.check(L.rm_debug_poison_queues(0, None))                                            # tag of the very next launch
         g = G.get(10, 0)
         assert _check(_render(hip, g, 10, 0, True, pipeline=2, suspend_after=(2, 6), team_grid=3), g, 10) == (0, 0), rnd
+
+
+def test_development_trace_of_a_single_launch(hip):
+    """rm_debug_set_trace / rm_debug_get_trace (the aid behind DESIGN.md section 3 "What a trace shows"): every ray a team
+    finishes leaves one record whose times are ordered (push <= pop <= end), whose iteration count is the frame's, and whose
+    pixel carries a start stamp; the frame itself is unchanged by tracing."""
+    import ctypes
+    L = hip.load()
+    g = golden_frames("160x120").get(10, 0)
+    w, h = g["W"], g["H"]
+    hip.check(L.rm_debug_set_trace(1))
+    try:
+        out = _render(hip, g, 10, 0, False, pipeline=2, suspend_after=(4, 12))
+        assert _check(out, g, 10) == (0, 0)
+        rec = np.empty((1 << 16, 8), np.uint32)
+        n = ctypes.c_int64(0)
+        start, detach = np.zeros(w * h, np.uint32), np.zeros(w * h, np.uint32)
+        t0 = ctypes.c_uint32(0)
+        vp = ctypes.c_void_p
+        hip.check(L.rm_debug_get_trace(rec.ctypes.data_as(vp), len(rec), ctypes.byref(n), start.ctypes.data_as(vp), detach.ctypes.data_as(vp),
+                                       w * h, ctypes.byref(t0)))
+    finally:
+        hip.check(L.rm_debug_set_trace(0))
+    rec = rec[: n.value]
+    assert 0 < n.value <= w * h
+    gi = rec[:, 0].astype(np.int64)
+    assert len(np.unique(gi)) == len(gi) and gi.max() < w * h                  # one record per ray
+    assert (rec[:, 1] == g["iters"].reshape(-1)[gi]).all()                    # iterations of that pixel
+    assert (rec[:, 2] <= rec[:, 3]).all() and (rec[:, 3] <= rec[:, 4]).all()  # push <= pop <= end (10 ns ticks since launch)
+    assert (rec[:, 5] <= rec[:, 6]).all() and (rec[:, 6] >= 12).all()          # evaluations at the pop / at the end; handed over at 12 trips
+    assert (start[gi] != 0).all() and (detach[gi] != 0).all()
+    again = _render(hip, g, 10, 0, False, pipeline=2, suspend_after=(4, 12))   # tracing off: same frame
+    assert (again["iters"] == out["iters"]).all()
