@@ -90,6 +90,18 @@ def test_product_never_imports_the_oracle():
                     assert needle not in text, (os.path.join(dp, f), needle)
 
 
+def test_tools_do_not_use_the_oracle_either():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load oracle/; the developer tools time and
+    trace the product, they do not check it."""
+    tools = os.path.join(ROOT, "tools")
+    for dp, _, files in os.walk(tools):
+        for f in files:
+            if f.endswith((".py", ".sh", ".hip")):
+                text = open(os.path.join(dp, f), encoding="utf-8", errors="replace").read()
+                for needle in ("import oracle", "from oracle", "librm_oracle", "rmo_"):
+                    assert needle not in text, (os.path.join(dp, f), needle)
+
+
 def test_shard_plan_in_c_equals_the_python_plan():
     """rm_shard_rows / the row plan rm_gather_frame checks == sharding.plan_rows (a host-only call)."""
     from raymarch_algo_compare_amd import sharding

@@ -32,7 +32,6 @@ def main():
     ap.add_argument("--tag", default="default")
     ap.add_argument("--late-teams", type=int, default=0)
     ap.add_argument("--exit-backlog", type=int, default=0)
-    ap.add_argument("--check", action="store_true", help="compare the iteration map with the CPU oracle (test infrastructure)")
     ap.add_argument("--brief", action="store_true")
     args = ap.parse_args()
     from raymarch_algo_compare_amd import _native, registry
@@ -111,17 +110,12 @@ def main():
         if m.any():
             byl[f"live {lo}-{hi}"] = {"rays": int(m.sum()), "pace_p50": round(float(np.percentile(pace[m], 50)), 1)}
     out["pace_by_team_load_at_end"] = byl
-    if args.check:
-        from oracle import oracle
-        ref = oracle.render(10, args.strategy, cam, W, H, nthreads=max(1, (os.cpu_count() or 2) - 1))
-        out["iter_mismatches_vs_oracle"] = int((ref.iters != iters).sum())
     if args.brief:
         lr = out["long_rays(>=500)"]
         print(json.dumps({"tag": args.tag, "frame_ms": round(out["frame_ms"], 3), "spans_ms": [round(v, 2) for v in spans],
                           "teams_rays": out["rays_through_teams"], "long_push_ms": lr["push_ms"], "long_wait_us": lr["queue_wait_us"],
                           "long_start_push_us": lr["start->push_us"], "long_team_ms": lr["team_ms"], "long_end_ms": lr["end_ms"],
-                          "pace_all": out["all_rays"]["team_pace_us_per_eval"], "last_ray": out["last_ray"],
-                          "mismatch": out.get("iter_mismatches_vs_oracle")}))
+                          "pace_all": out["all_rays"]["team_pace_us_per_eval"], "last_ray": out["last_ray"]}))
     else:
         print(json.dumps(out, indent=1))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
