@@ -182,8 +182,12 @@ __device__ __forceinline__ int rank_in_mask(unsigned long long m)
 __device__ __forceinline__ void store_raw(const KernelArgs& a, uint32_t gi, const Result& r, int nev)
 {
     if (a.t_raw) a.t_raw[gi] = r.t;
+#ifdef RM_DEV_STAMP      // development (tools/ray_times.py): `evals` = finish time, `final_sdf` = start time, 100 MHz device clock
+    if (a.evals) a.evals[gi] = (int)(__builtin_amdgcn_s_memrealtime() & 0x3fffffffull);
+#else
     if (a.final_sdf) a.final_sdf[gi] = r.final_sdf;
     if (a.evals) a.evals[gi] = nev;
+#endif
 }
 
 constexpr int kWavesPerWG = 4;         // 256-thread workgroups: four waves share one LDS copy of the libm tables
@@ -581,6 +585,9 @@ __global__ __launch_bounds__(64 * kWavesPerWG, 2) void render_kernel(const Kerne
                             camera_ray(a.single.cam, a.width, a.height, cg.x0 + px, cg.gy0 + py, origin, dir);
                         }
                         nev = 0;
+#ifdef RM_DEV_STAMP
+                        if (a.final_sdf) a.final_sdf[my_gi] = (double)(__builtin_amdgcn_s_memrealtime() & 0x3fffffffull);
+#endif
                         if (s.start(cfg)) {
                             s_depth[cur][my_pix] = s.res.hit ? (float)s.res.t : 0.0f;
                             s_ih[cur][my_pix] = (uint32_t)s.res.iters | ((uint32_t)s.res.hit << 31);
