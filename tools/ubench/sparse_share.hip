@@ -56,14 +56,26 @@ void run(const char* name, vec3 o, vec3 d)
 // The frame in small: every wave first marches with all 64 lanes (`dense` rays one after the other: the dense phase), then only
 // its lane 0 goes on (the tail); the pace of wave 0's tail is recorded ray by ray (a ray = 352 iterations ~ 0.12 ms).
 template <class Scene>
-__global__ __launch_bounds__(768) void phases(MarchCfg cfg, vec3 o, vec3 d, int dense, int segs, double* out, float* pace)
+__global__ __launch_bounds__(768) void phases(MarchCfg cfg, vec3 o, vec3 d, int dense, int segs, int filler, double* out, float* pace)
 {
+    __shared__ unsigned int s_done;
+    if (threadIdx.x == 0) s_done = 0u;
     rm_load_tables<Scene>();
     __syncthreads();
     const int lane = lane_id();
     double acc = 0.0;
     for (int r = 0; r < dense; ++r) acc += march_one<Scene, StratStandard>(o, v3(d.x + acc * 1e-300, d.y, d.z), cfg).t;
-    if (lane == 0) {
+    if (filler && threadIdx.x >= 64 * filler) {
+        // filler waves: instead of idling through the tail they keep all 64 lanes of their SIMD's fp64 pipe busy until wave 0 is done
+        double x0 = acc + lane, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3;
+        while (__hip_atomic_load(&s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {
+            for (int i = 0; i < 64; ++i) {
+                x0 = __builtin_fma(x0, 1.0000001, 1e-9); x1 = __builtin_fma(x1, 1.0000001, 1e-9);
+                x2 = __builtin_fma(x2, 1.0000001, 1e-9); x3 = __builtin_fma(x3, 1.0000001, 1e-9);
+            }
+        }
+        acc += x0 + x1 + x2 + x3;
+    } else if (lane == 0) {
         for (int sgm = 0; sgm < segs; ++sgm) {
             const long long t0 = __builtin_amdgcn_s_memrealtime();
             const Result res = march_one<Scene, StratStandard>(o, v3(d.x + acc * 1e-300, d.y, d.z), cfg);
@@ -71,6 +83,7 @@ __global__ __launch_bounds__(768) void phases(MarchCfg cfg, vec3 o, vec3 d, int 
             acc += res.t;
             if (threadIdx.x == 0 && blockIdx.x == 0) pace[sgm] = (float)((t1 - t0) / 100.0 / res.iters);
         }
+        if (threadIdx.x == 0) __hip_atomic_store(&s_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     out[threadIdx.x] = acc;
 }
@@ -88,14 +101,15 @@ void run_phases(vec3 o, vec3 d)
     d = v3(d.x * n, d.y * n, d.z * n);
     for (int pass = 0; pass < 2; ++pass)
         for (int grid : { 1, 256 })
+            for (int filler : { 0, 4, 1 })
             for (int dense : { 0, 2, 20 }) {
-                hipLaunchKernelGGL(phases<Scene>, dim3(grid), dim3(768), 0, 0, cfg, o, d, dense, segs, out, pace);
+                hipLaunchKernelGGL(phases<Scene>, dim3(grid), dim3(768), 0, 0, cfg, o, d, dense, segs, filler, out, pace);
                 (void)hipDeviceSynchronize();
                 float h[24];
                 (void)hipMemcpy(h, pace, 4 * segs, hipMemcpyDeviceToHost);
                 if (pass == 1) {
-                    printf("%3d workgroups x 12 waves, %2d dense rays first (%.1f ms), then lane 0 only, us per iteration ray by ray:", grid, dense,
-                           dense * 352 * 0.334e-3);
+                    printf("%3d workgroups x 12 waves, %2d dense rays first (%.1f ms), then lane 0 of %s (fp64 filler in the others: %s), us per iteration ray by ray:",
+                           grid, dense, dense * 352 * 0.334e-3, filler == 1 ? "wave 0" : filler == 4 ? "waves 0-3" : "every wave", filler ? "yes" : "no");
                     for (int i = 0; i < segs; ++i) printf(" %.2f", h[i]);
                     printf("\n");
                 }
