@@ -99,9 +99,10 @@ def csrc_fingerprint():
 
 
 def idle_team_pace(L, _native, scene_id, strat_id, cam14, W, H, iters_map, lip):
-    """The frame's own longest rays (>= 500 iterations) marched again by wavefront teams on an otherwise idle device
-    (rm_march_rays_team: three waves per 64 rays, nothing else resident): wall time of the call / iterations of the
-    longest ray = microseconds per evaluation of a dependent chain at its best -- the floor a frame cannot go below."""
+    """The frame's own longest rays (>= 500 iterations) marched again by wavefront teams with nothing else to do
+    (rm_march_rays_team: three waves per 64 rays; filler workgroups keep the rest of the chip busy, as a frame's finished
+    producers do -- KEEP BUSY, csrc/rm_kernels.h): wall time of the call / iterations of the longest ray = microseconds per
+    evaluation of a dependent chain at its best -- the floor a frame cannot go below."""
     import numpy as np
     ys, xs = np.nonzero(iters_map >= 500)
     if len(ys) == 0:
@@ -391,8 +392,8 @@ def main():
                                  "(DESIGN.md); store_path_* = the flush code alone at this frame size, store_path_8k_* = the "
                                  "same at 7680x4320"},
         }
-        # the longest ray is one dependent chain: iter_max evaluations, each as fast as a wavefront team runs it on an idle
-        # device -- measured here, on the frame's own longest rays (idle_team_pace)
+        # the longest ray is one dependent chain: iter_max evaluations, each as fast as a wavefront team runs it when it is
+        # all there is to run -- measured here, on the frame's own longest rays (idle_team_pace)
         if pace is not None and "us_per_evaluation" in pace:
             chain_floor_ms = float(st.iter_max) * pace["us_per_evaluation"] * 1e-3
             line["chain_latency"] = {"iter_max": int(st.iter_max), "idle_team": pace, "floor_ms": chain_floor_ms,

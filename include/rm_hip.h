@@ -184,6 +184,16 @@ typedef struct RmFrameDesc {
      * Results are identical for every setting. */
     int32_t late_teams;
     int32_t exit_backlog;
+    /* KEEP BUSY.  The same march loop runs at two speeds on this chip: the full one while most compute units execute
+     * vector instructions, and 15-60 % slower when few wavefronts are live (tools/ubench/
+     * sparse_share.hip) -- which is exactly the state of a frame whose last long rays are finished by a few team
+     * wavefronts.  With keep_busy the workgroups that have run out of work do not leave: they execute `keep_busy`
+     * fp32 multiply-adds per lane between two looks at a counter until the teams are through (bounded: 30 ms), and
+     * the chains of the long rays run at the full speed (Mandelbulb 1920x1080: 9.4 -> 8.1 ms).  0 = library default
+     * (256 in launches that end with teams, off elsewhere: where other workgroups still render tiles the filler only
+     * takes their issue slots), < 0 = off, > 0 = explicit burst length.  Results are identical for every setting. */
+    int32_t keep_busy;
+    int32_t reserved0;
 } RmFrameDesc;
 
 /* Frame reduce computed in-kernel (the integer part of RayMarchStats.compute, core/types.py:77-137). */

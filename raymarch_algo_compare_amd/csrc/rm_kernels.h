@@ -60,7 +60,8 @@ constexpr int kStatsBlocks = 1 + kStatsParts;
 // device-side stats block (u64 words):
 //  [0] tile counter   [1] hit_count   [2] sum_iters   [3] iter_max   [4] 0x7fffffff - iter_min
 //  [5] rays written   [6..7] entries pushed to suspended-ray queue 0 / 1   [8..9] entries handed out
-//  of queue 0 / 1   [10] SDF evaluations of the finished rays   [11] fused-reduce tickets   [12] reserved
+//  of queue 0 / 1   [10] SDF evaluations of the finished rays   [11] fused-reduce tickets
+//  [12], [13] team passes (resume_team_kernel, level 0 / 1): team workgroups that have left (KernelArgs.keep_busy)
 //  [13..15], [17..23] single-launch pipeline: time marks (rm_pipeline.h; written only when KernelArgs.marks)
 //  [16] pipeline protocol error (0 = none)
 //  [kStatsHead .. kStatsHead + kHistBins) = [24 .. 568) histogram of iterations
@@ -153,6 +154,8 @@ struct KernelArgs {
     int32_t team_prio;          // s_setprio level of the team waves (0..3)
     int32_t age_prio;           // > 0: a producer wave's issue priority = (trips of its oldest ray) / age_prio, capped at 2
     int32_t marks;              // single launch: waves leave device-clock marks in stats block 0 (rm_set_pass_timing); off in production
+    int32_t keep_busy;          // > 0: workgroups without work stay and execute this many fp32 fmas per lane between two looks at
+                                // the count of finished team workgroups (keep_busy_until below; RmFrameDesc.keep_busy)
     // Roles that change during the launch (rm_pipeline.h "late teams"): workgroups [late_team_first, gridDim.x) are teams
     // the dispatcher starts when producer workgroups have left; producer workgroups [team_wgs, team_wgs + early_exit_wgs)
     // leave (stop taking tiles, hand their detached rays to queue 1) once queue 1 holds exit_backlog rays per pending
@@ -191,6 +194,30 @@ __device__ __forceinline__ void store_raw(const KernelArgs& a, uint32_t gi, cons
 }
 
 constexpr int kWavesPerWG = 4;         // 256-thread workgroups: four waves share one LDS copy of the libm tables
+
+// KEEP BUSY (RmFrameDesc.keep_busy, include/rm_hip.h).  This chip runs the same instruction stream at two speeds: the full
+// one while most compute units execute vector instructions, a 15-60 % slower one when few wavefronts are live -- the state
+// of a launch whose last long rays are being finished by a few team wavefronts (tools/ubench/sparse_share.hip: Sphere's
+// march loop 0.34 against 0.52-0.60 us per iteration, the Mandelbulb's 10.0 against 11.5-12.4; what matters is vector work on
+// many lanes -- fp64, fp32 or integer alike -- not waves that merely stay resident: s_sleep in the same place gains nothing).
+// A wave that has nothing left to do therefore stays and executes `burst` fp32 fmas on all 64 lanes between two looks at
+// *done, until `target` team workgroups have reported or 30 ms of the 100 MHz clock have passed (no wait is unbounded).
+__device__ __forceinline__ void keep_busy_until(const unsigned long long* done, unsigned long long target, int burst)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    float f0 = (float)lane_id(), f1 = f0 + 1.0f, f2 = f0 + 2.0f, f3 = f0 + 3.0f;
+    for (;;) {
+        unsigned long long n = 0;
+        if (lane_id() == 0) n = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        n = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)n);
+        if (n >= target || __builtin_amdgcn_s_memrealtime() - t0 > 3000000ull) break;
+        for (int i = 0; i < burst; ++i) {
+            f0 = __builtin_fmaf(f0, 1.0000001f, 1e-9f); f1 = __builtin_fmaf(f1, 1.0000001f, 1e-9f);
+            f2 = __builtin_fmaf(f2, 1.0000001f, 1e-9f); f3 = __builtin_fmaf(f3, 1.0000001f, 1e-9f);
+        }
+    }
+    asm volatile("" :: "v"(f0), "v"(f1), "v"(f2), "v"(f3));      // the values are never used; the loop must stay
+}
 
 // Copy the gathered libm tables this scene needs from constant memory into LDS (all threads of the
 // workgroup cooperate; ends with a barrier).  With RM_TABLES_IN_LDS the math headers read rm_s_*.
@@ -896,9 +923,16 @@ __device__ __forceinline__ bool team_trip(typename Scene::Eval& ev, bool go, int
 template <class Scene, class Strat>
 __global__ __launch_bounds__(64 * kTeam) void march_rays_team_kernel(MarchCfg cfg, const double* __restrict__ origins,
                                                                      const double* __restrict__ dirs, size_t n, uint8_t* hit,
-                                                                     double* t, int32_t* iters, double* final_sdf)
+                                                                     double* t, int32_t* iters, double* final_sdf,
+                                                                     unsigned long long* busy)
 {
     __shared__ TeamXch xch;
+    // workgroups behind the teams only keep the chip busy until the teams are through (KEEP BUSY above; busy = nullptr: none)
+    const unsigned int nteams = (unsigned int)((n + 63) / 64);
+    if (blockIdx.x >= nteams) {
+        if (busy) keep_busy_until(busy, (unsigned long long)nteams, 256);
+        return;
+    }
     rm_load_tables<Scene>();
     const int lane = lane_id();
     const int part = (int)(threadIdx.x >> 6);
@@ -926,6 +960,7 @@ __global__ __launch_bounds__(64 * kTeam) void march_rays_team_kernel(MarchCfg cf
     if (have && part == 0) {
         hit[i] = (uint8_t)s.res.hit; t[i] = s.res.t; iters[i] = s.res.iters; final_sdf[i] = s.res.final_sdf;
     }
+    if (busy && threadIdx.x == 0) __hip_atomic_fetch_add(busy, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // resume_kernel for teams: one team per workgroup carries 64 parked rays at a time; every wave holds
@@ -949,6 +984,17 @@ __global__ __launch_bounds__(64 * kTeam) void resume_team_kernel(const KernelArg
     const unsigned int count = (unsigned int)min(pushed, (unsigned long long)a.queue_cap);
     const Entry* const queue = (const Entry*)a.queue[level];
     const uint32_t frame_elems = (uint32_t)a.rows * (uint32_t)a.width;
+    // KEEP BUSY (above): the workgroups behind the a.team_wgs teams of this pass wait until the queue is handed out -- while
+    // the teams are full, filler would only take their issue slots -- and then keep their compute units busy until the
+    // teams have reported in stats word 12 + level.
+    if (a.keep_busy > 0 && (int)blockIdx.x >= a.team_wgs) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(&a.stats[8 + level], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)count &&
+               __builtin_amdgcn_s_memrealtime() - t0 < 3000000ull)
+            __builtin_amdgcn_s_sleep(127);
+        keep_busy_until(&a.stats[12 + level], (unsigned long long)a.team_wgs, a.keep_busy);
+        return;
+    }
 
     WaveAcc acc;
     bool more = count > 0;
@@ -1068,6 +1114,7 @@ __global__ __launch_bounds__(64 * kTeam) void resume_team_kernel(const KernelArg
         const unsigned int c = s_hist[b];
         if (c) atomicAdd(&spart[kStatsHead + b], (unsigned long long)c);
     }
+    if (a.keep_busy > 0 && threadIdx.x == 0) __hip_atomic_fetch_add(&a.stats[12 + level], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Per-scene launch table, filled by rm_scene_tu.hip (one translation unit per scene).
@@ -1083,8 +1130,9 @@ struct SceneLaunchers {
     hipError_t (*sdf_eval)(const double* xyz, size_t n, double* out, hipStream_t s);
     hipError_t (*march_rays)(int strategy, const MarchCfg& cfg, const double* o, const double* d, size_t n,
                              uint8_t* hit, double* t, int32_t* iters, double* fs, hipStream_t s);
+    // nullptr: no team form.  busy: a zeroed device word -> `fillers` more workgroups keep the chip busy until the teams are through
     hipError_t (*march_rays_team)(int strategy, const MarchCfg& cfg, const double* o, const double* d, size_t n,
-                                  uint8_t* hit, double* t, int32_t* iters, double* fs, hipStream_t s);   // nullptr: no team form
+                                  uint8_t* hit, double* t, int32_t* iters, double* fs, unsigned long long* busy, int fillers, hipStream_t s);
 };
 
 }  // namespace rm

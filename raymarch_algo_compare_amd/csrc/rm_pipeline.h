@@ -65,7 +65,8 @@ constexpr int kCFreshDone = 5;    // producer waves that have finished (or never
 constexpr int kCProdExited = 6;   // producer waves that have left their loop
 constexpr int kCLeft = 7;         // early-exit producer workgroups that have decided to leave (late teams take their place)
 constexpr int kCLateStarted = 8;  // late team workgroups that have started
-constexpr int kCtlWords = 9 * kCtlStride;
+constexpr int kCTeamDone = 9;     // team workgroups that have left (KernelArgs.keep_busy: finished producers stay until all have)
+constexpr int kCtlWords = 10 * kCtlStride;
 __device__ __forceinline__ unsigned long long* ctl(const KernelArgs& a, int k) { return a.ctl + k * kCtlStride; }
 // words of stats block 0 written once per wave (see the layout comment in rm_kernels.h)
 constexpr int kWMarkStart = 13;   // ~min s_memrealtime at kernel entry            } 100 MHz device clock,
@@ -494,6 +495,7 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
             const unsigned int c = L.hist[b];
             if (c) atomicAdd(&spart[kStatsHead + b], (unsigned long long)c);
         }
+        if (part == 0 && lane == 0) __hip_atomic_fetch_add(ctl(a, kCTeamDone), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     }
@@ -905,6 +907,8 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
         const unsigned int c = s_hist[b];
         if (c) atomicAdd(&part[kStatsHead + b], (unsigned long long)c);
     }
+    // a finished producer workgroup keeps its compute unit's lanes busy until the teams are through (KEEP BUSY, rm_kernels.h)
+    if (TEAMS && a.keep_busy > 0 && !team_wg && a.team_wgs > 0) keep_busy_until(ctl(a, kCTeamDone), (unsigned long long)a.team_wgs, a.keep_busy);
 }
 
 }  // namespace rm

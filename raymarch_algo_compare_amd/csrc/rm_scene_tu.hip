@@ -205,15 +205,16 @@ static hipError_t march_rays(int strategy, const MarchCfg& cfg, const double* o,
 
 template <bool ITER>
 static hipError_t march_rays_team_impl(int strategy, const MarchCfg& cfg, const double* o, const double* d, size_t n,
-                                       uint8_t* hit, double* t, int32_t* iters, double* fs, hipStream_t s)
+                                       uint8_t* hit, double* t, int32_t* iters, double* fs, unsigned long long* busy, int fillers,
+                                       hipStream_t s)
 {
     if constexpr (ITER) {
         if (n == 0) return hipSuccess;
-        dim3 grid((unsigned)((n + 63) / 64)), block(64 * kTeam);
+        dim3 grid((unsigned)((n + 63) / 64) + (unsigned)(busy ? fillers : 0)), block(64 * kTeam);
         switch (strategy) {
 #define RM_X(id, S)                                                                                             \
     case id:                                                                                                    \
-        hipLaunchKernelGGL((march_rays_team_kernel<SceneT, S>), grid, block, 0, s, cfg, o, d, n, hit, t, iters, fs); \
+        hipLaunchKernelGGL((march_rays_team_kernel<SceneT, S>), grid, block, 0, s, cfg, o, d, n, hit, t, iters, fs, busy); \
         return hipGetLastError();
             RM_STRATEGY_LIST(RM_X)
 #undef RM_X

@@ -95,29 +95,34 @@ void run_phases(vec3 o, vec3 d)
     cfg.hit_threshold = 1e-4; cfg.max_distance = 100.0; cfg.lipschitz = 1.0; cfg.max_iterations = 512; cfg.full = 0;
     cfg.prm = default_strat_params();
     double* out; float* pace;
-    const int segs = 24;
-    if (hipMalloc(&out, 8 * 768) != hipSuccess || hipMalloc(&pace, 4 * segs) != hipSuccess) return;
+    const int segs = SceneIterative<Scene>::value ? 6 : 24;
+    if (hipMalloc(&out, 8 * 768) != hipSuccess || hipMalloc(&pace, 4 * 24) != hipSuccess) return;
     const double n = 1.0 / __builtin_sqrt(d.x * d.x + d.y * d.y + d.z * d.z);
     d = v3(d.x * n, d.y * n, d.z * n);
+    const bool bulb = SceneIterative<Scene>::value;
     for (int pass = 0; pass < 2; ++pass)
         for (int grid : { 1, 256 })
             for (int filler : { 0, 4, 1 })
-            for (int dense : { 0, 2, 20 }) {
+            for (int dense : { 0, bulb ? 1 : 2, bulb ? 2 : 20 }) {
                 hipLaunchKernelGGL(phases<Scene>, dim3(grid), dim3(768), 0, 0, cfg, o, d, dense, segs, filler, out, pace);
                 (void)hipDeviceSynchronize();
                 float h[24];
                 (void)hipMemcpy(h, pace, 4 * segs, hipMemcpyDeviceToHost);
                 if (pass == 1) {
                     printf("%3d workgroups x 12 waves, %2d dense rays first (%.1f ms), then lane 0 of %s (fp64 filler in the others: %s), us per iteration ray by ray:",
-                           grid, dense, dense * 352 * 0.334e-3, filler == 1 ? "wave 0" : filler == 4 ? "waves 0-3" : "every wave", filler ? "yes" : "no");
+                           grid, dense, dense * (SceneIterative<Scene>::value ? 512 * 3.0e-3 : 352 * 0.334e-3), filler == 1 ? "wave 0" : filler == 4 ? "waves 0-3" : "every wave", filler ? "yes" : "no");
                     for (int i = 0; i < segs; ++i) printf(" %.2f", h[i]);
                     printf("\n");
                 }
             }
 }
 
-int main()
+int main(int argc, char** argv)
 {
+    if (argc > 1) {      // any argument: the Mandelbulb's 512-iteration ray of pixel (240, 128) at 480x270 instead (one wave: whole evaluations)
+        run_phases<SceneMandelbulb>(v3(0.0, 0.0, 3.0), v3(0.0021383343303320534, 0.02779834629431532, -1.0));
+        return 0;
+    }
     run_phases<SceneSphere>(v3(0.0, 0.0, 5.0), v3(-0.20153801063378607, 0.032609598537562186, -1.0));
     run<SceneSphere>("Sphere", v3(0.0, 0.0, 5.0), v3(-0.20153801063378607, 0.032609598537562186, -1.0));
     return 0;
