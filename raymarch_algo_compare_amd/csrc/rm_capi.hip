@@ -424,7 +424,7 @@ void suspend_levels(const RmFrameDesc* d, long long rays, int mode, int* park)
     // Gyroid (three sincos per evaluation, long skimming rays inside the ball) parked at 24 trips in round 1 (1.88 ->
     // 1.63 ms in natural tile order).  With the centre-out order its long rays start early anyway: parking measured
     // 1.63 vs 1.60 ms without (Adaptive-Hybrid 1.17 vs 1.05), so it no longer parks.
-    // Single launch (Mandelbulb): rays are struck from their tile at 16 trips (the tile slot is free again) and handed
+    // Single launch (Mandelbulb): rays are struck from their tile at 24 trips (16 until round 3) (the tile slot is free again) and handed
     // to the teams at 48; larger frames, and Segment whose trips evaluate twice, at 32 / 64.  Every strategy gains,
     // Overstep-Bisect and Skipping-Spheres included (3.56 -> 3.08 ms, 11.3 -> 10.2 ms).
     if (mode == 2 && d->scene_id == 10 && d->march.max_iterations > 128) {
@@ -432,7 +432,10 @@ void suspend_levels(const RmFrameDesc* d, long long rays, int mode, int* park)
         // 7.3-7.5 ms, 32 / 64 7.5-7.6, 16 / 48 8.5)
         const bool small = rays <= 3000000ll && d->strategy_id != 10 && d->tile_order_mode != 1;
         const bool ordered = rays <= 3000000ll && d->strategy_id != 10 && d->tile_order_mode == 1;
-        if (d->suspend_after[0] == 0) park[0] = small ? 16 : (ordered ? 24 : 32);
+        // (strike at 24 instead of 16, round 3: the same time over the Mandelbulb's three curated viewpoints x Standard / Enhanced /
+        // Adaptive-Hybrid -- sums 28.98 / 21.30 / 17.00 ms against 28.96 / 21.32 / 16.93, profiles/r03/viewpoint_budgets.jsonl -- and
+        // half as many rays finish outside their tile: 385 k instead of 738 k scattered 9-byte results per 1080p frame)
+        if (d->suspend_after[0] == 0) park[0] = small ? 24 : (ordered ? 24 : 32);
         if (d->suspend_after[1] == 0 && d->suspend_after[0] == 0) park[1] = small ? 48 : (ordered ? 56 : 64);
     }
     if (park[0] == 0) park[1] = 0;
@@ -676,7 +679,7 @@ int launch_frame(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, h
         a.q0_first = d->queue_first == 0 ? 1 : (d->queue_first == 1 ? 1 : 0);
         a.q0_refill_min = d->queue_refill_min > 0 ? d->queue_refill_min : 16;
         a.q0_retry = d->queue_retry > 0 ? d->queue_retry : 16;
-        a.team_retry = d->team_retry > 0 ? d->team_retry : 4;
+        a.team_retry = d->team_retry > 0 ? d->team_retry : 8;      // (with keep_busy: 2: 8.29, 4: 8.19, 8: 7.97, 16: 8.12, 32: 8.33 ms; other strategies flat)
         a.team_steal = d->team_steal == 0 ? 1 : (d->team_steal == 1 ? 1 : 0);
         a.max_spins = 50000;
         a.marks = (g.pass_timing || g.tracing) ? 1 : 0;      // device-clock marks only when somebody will read them (rm_get_pass_ms)

@@ -33,10 +33,11 @@
 //
 // Queue protocol (cdna_hip_programming.md Guideline 16, recipe R1; no order of dispatch, placement or
 // co-residency is assumed):
-//   push   lane 0 reserves slots with one agent-scope atomic add -> lanes write their entries with
-//          WRITE-THROUGH stores (8-byte relaxed agent-scope atomic stores = `global_store_dwordx2 sc1`:
-//          no release fence, so the frame's own dirty output lines are never written back early) ->
-//          s_waitcnt vmcnt(0) -> every lane stores its entry's `ready` word = this launch's generation
+//   push   lane 0 reserves slots with one agent-scope atomic add -> the entries are written with
+//          WRITE-THROUGH stores (`global_store_dwordx4 sc1`, what a relaxed agent-scope atomic store compiles to, 16 bytes
+//          wide: no release fence, so the frame's own dirty output lines are never written back early; every entry as ONE
+//          contiguous run stored by a few lanes, see q_push) ->
+//          s_waitcnt vmcnt(0) -> every pushing lane stores its entry's `ready` word = this launch's generation
 //          tag (relaxed agent-scope store);
 //   pop    lane 0 claims [taken, min(taken + n, reserved)) with a compare-and-swap -> every lane polls
 //          the `ready` word of its entry (relaxed agent-scope loads; the writer is between its reserve
@@ -169,23 +170,51 @@ __device__ __forceinline__ bool q_push(const KernelArgs& a, int q, bool want, ui
     const bool ok = want && idx < (unsigned long long)a.queue_cap;
     static_assert(sizeof(QEntry<Strat>) % 8 == 0 && alignof(QEntry<Strat>) == 8, "entries are copied as 8-byte words");
     constexpr int NW = (int)(sizeof(QEntry<Strat>) / 8);
+    constexpr int NP = (NW + 1) / 2;                          // 16-byte pieces of an entry (the last one 8 bytes when NW is odd)
     unsigned long long* const dst = (unsigned long long*)((QEntry<Strat>*)a.queue[q] + (ok ? idx : 0ull));
-    if (ok) {
+    unsigned long long w[NW];
+    {
         QEntry<Strat> e;
         e.gi = gi;
         e.nev = (uint32_t)nev;
-        e.ready = 0u;
+        e.ready = 0u;                                         // never a generation tag: the entry stays unpublished until the flag store below
         e.pad = a.marks ? (uint32_t)(realtime() - ~ld_relaxed(&a.stats[kWMarkStart])) : 0u;      // push time since launch (tuning marks)
         e.s = s;
-        unsigned long long w[NW];
         __builtin_memcpy(w, &e, sizeof e);
-        // word 1 holds `ready`: written last, on its own
-#pragma unroll
-        for (int k = 0; k < NW; ++k)
-            if (k != 1) __hip_atomic_store(dst + k, w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store((uint32_t*)(dst + 1) + 1, e.pad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // upper half of word 1
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing lane's entry has left the wave
+    // ONE RUN OF BYTES PER ENTRY.  A lane that stored its own entry word by word issued NW write-through stores of 8 bytes, and
+    // the memory side counts every one of them as a request of its own: 377 bytes of HBM write traffic per 72-byte entry, 34 of
+    // the 54 MB a 1080p Mandelbulb frame wrote (tools/traffic_variants.sh).  Instead the entry of every pushing lane travels
+    // through scalar registers to lanes 0 .. NP-1, which store 16 bytes each: one contiguous run, one or two requests.
+    const int lane = lane_id();
+    for (unsigned long long mm = __ballot(ok); mm != 0; mm &= mm - 1) {      // wave-uniform
+        const int src = (int)__builtin_ctzll(mm);
+        const unsigned int ilo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)idx, src);
+        const unsigned int ihi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(idx >> 32), src);
+        unsigned int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const unsigned int a0 = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)w[2 * p], src);
+            const unsigned int a1 = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(w[2 * p] >> 32), src);
+            unsigned int a2 = 0, a3 = 0;
+            if (2 * p + 1 < NW) {
+                a2 = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)w[2 * p + 1], src);
+                a3 = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(w[2 * p + 1] >> 32), src);
+            }
+            if (lane == p) { p0 = a0; p1 = a1; p2 = a2; p3 = a3; }
+        }
+        char* const d = (char*)((QEntry<Strat>*)a.queue[q] + (((unsigned long long)ihi << 32) | ilo)) + 16 * lane;
+        if (lane < NP) {
+            if ((NW & 1) && lane == NP - 1) {
+                __hip_atomic_store((unsigned long long*)d, ((unsigned long long)p1 << 32) | p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 v = { p0, p1, p2, p3 };
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(d), "v"(v) : "memory");      // write-through, like the atomic stores
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every entry has left the wave
     if (ok) __hip_atomic_store((uint32_t*)(dst + 1), a.generation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a.marks && q == 1 && lane_id() == 0) atomicMax(&a.stats[kWMarkPush], realtime());
     return ok;
