@@ -626,6 +626,9 @@ int launch_frame(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, h
             // Small frames are all tail (the chains of the long rays): more teams; large frames are fresh-pixel
             // throughput with a short tail: more producers.
             long long share16 = rays_total <= 1000000ll ? 7 : (rays_total <= 3000000ll ? 6 : 3);      // sixteenths of the grid
+            // (with keep_busy, over the three curated viewpoints: 1280x720 wants 128-160 teams, not 224 -- Enhanced 17.6 -> 15.6 ms in
+            // the sum at 128, Relaxed / Auto-Relaxed / Slope / Curvature 2-5 % at 160, Standard flat; 960x540 and 1920x1080 stay)
+            if (rays_total > 600000ll && rays_total <= 1000000ll) share16 = d->strategy_id == 4 ? 4 : 5;
             if (d->tile_order_mode == 1 && rays_total <= 3000000ll) share16 = 7;                      // (15/32 measured 2 % better still)
             if (a.nframes > 1 && rays_total > 3000000ll) share16 = 4;        // sweeps: 64 x 384^2 viewpoints 29.0 ms (96: 31, 192: 34.6)
             // Strategies whose rays end early hand few rays to the teams: Overstep-Bisect 2.95 / 3.03 / 3.32 ms and

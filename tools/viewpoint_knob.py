@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Is a schedule default viewpoint-robust?  Every curated viewpoint of one scene (viewpoints.py) at 1920x1080, a few
 strategies: device time per frame over the values of ONE RmFrameDesc knob (pairs as a:b; 0 or 0:0 = the library's choice).
-  python tools/viewpoint_knob.py <scene_id> <knob> "<v0,v1,...>" ["<strategy ids>"]
+  python tools/viewpoint_knob.py <scene_id> <knob> "<v0,v1,...>" ["<strategy ids>" [WxH]]
   python tools/viewpoint_knob.py 10 suspend_after "0:0,16:48,16:40,24:40,24:48,32:48,24:56" "0,4,9"    # profiles/r03/viewpoint_budgets.jsonl
   python tools/viewpoint_knob.py 10 tile_order_mode "0,2,3,4" "0,4,9,6"
 (timing only: every value yields the same frames)"""
@@ -24,6 +24,8 @@ def val(v):
 sc = registry.SCENES[int(sys.argv[1])]
 knob, values = sys.argv[2], [val(v) for v in sys.argv[3].split(",")]
 strategies = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0, 4, 9]
+if len(sys.argv) > 5:
+    W, H = (int(v) for v in sys.argv[5].split("x"))
 _native.init()
 total = {}
 for vp in viewpoints_for(sc):
