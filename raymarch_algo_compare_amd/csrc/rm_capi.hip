@@ -100,6 +100,7 @@ struct State {
     bool events = false;
     Buf bstats;   // rm_render_batch: the device frame table
     Buf ctl;      // single-launch pipeline: its hot counters, one per 128-byte line
+    Buf busy;     // rm_march_rays_team: the counter its filler workgroups watch (its own word: a frame in flight owns `ctl`)
     Buf trace, trace_start, trace_detach;   // development trace of single-launch frames (rm_debug_set_trace)
     bool tracing = false;
     size_t trace_pix = 0;
@@ -980,7 +981,7 @@ void rm_shutdown(void)
     for (auto& k : g.qkey) k = State::QueueKey();
     g.tracing = false;
     g_seen_streams.clear();
-    for (Buf* b : { &g.trace, &g.trace_start, &g.trace_detach, &g.ccost, &g.corder, &g.ctl, &g.bstats, &g.stats, &g.depth, &g.iters, &g.hit, &g.traw, &g.fs, &g.bvar, &g.evals, &g.in0, &g.in1, &g.out0, &g.out1,
+    for (Buf* b : { &g.trace, &g.trace_start, &g.trace_detach, &g.ccost, &g.corder, &g.ctl, &g.busy, &g.bstats, &g.stats, &g.depth, &g.iters, &g.hit, &g.traw, &g.fs, &g.bvar, &g.evals, &g.in0, &g.in1, &g.out0, &g.out1,
                     &g.out2, &g.out3, &g.tcost, &g.torder, &g.queue[0], &g.queue[1] })
         b->release();
     if (g.frame_ev_valid) (void)hipEventDestroy(g.frame_ev);
@@ -1054,13 +1055,13 @@ static int march_rays_impl(bool team, int scene_id, int strategy_id, const RmMar
     if (team) {
         // the teams of a few rays are all that runs: filler workgroups (two per compute unit in all) keep the chip at the
         // speed a frame's teams run at (KEEP BUSY, rm_kernels.h) -- rm_march_rays_team is how bench.py measures a chain
-        if ((rc = g.ctl.ensure(sizeof(unsigned long long) * rm::kCtlWords))) return rc;
-        HIP_TRY(hipMemsetAsync(g.ctl.p, 0, sizeof(unsigned long long), g.stream));
+        if ((rc = g.busy.ensure(128))) return rc;
+        HIP_TRY(hipMemsetAsync(g.busy.p, 0, sizeof(unsigned long long), g.stream));
         const long long nteams = (long long)((n + 63) / 64);
         const int fillers = (int)std::max<long long>(0, 2ll * g.prop.multiProcessorCount - nteams);
         HIP_TRY(rm::scene(scene_id)->march_rays_team(strategy_id, c, (const double*)g.in0.p, (const double*)g.in1.p, n, (uint8_t*)g.out0.p,
                                                      (double*)g.out1.p, (int32_t*)g.out2.p, (double*)g.out3.p,
-                                                     (unsigned long long*)g.ctl.p, fillers, g.stream));
+                                                     (unsigned long long*)g.busy.p, fillers, g.stream));
     } else {
         HIP_TRY(rm::scene(scene_id)->march_rays(strategy_id, c, (const double*)g.in0.p, (const double*)g.in1.p, n, (uint8_t*)g.out0.p,
                                                 (double*)g.out1.p, (int32_t*)g.out2.p, (double*)g.out3.p, g.stream));
