@@ -377,7 +377,11 @@ def main():
                                    f"camera {scene.camera_position or (0.0, 0.0, 5.0)}",
                        "frames_per_step": 1 if wl["sharded"] else world,
                        "rays_per_step": int(rays_step),
-                       "parallelism": (f"rowshard{world}-bandcyclic4+allgather" if wl["sharded"] else f"frame-per-gpu x{world}")},
+                       "parallelism": (f"rowshard{world}-bandcyclic4+allgather" if wl["sharded"] else f"frame-per-gpu x{world}"),
+                       "schedule": ("library defaults (RmFrameDesc knobs all 0): one launch per frame, tile order centre-out, rays struck "
+                                    "from their tile at 24 trips and handed to wavefront teams at 48, keep_busy on (finished producer "
+                                    "workgroups execute fp32 filler until the teams are through: include/rm_hip.h)")
+                                   if scene.id == 10 and not wl["sharded"] else "library defaults (RmFrameDesc knobs all 0)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms_avg": kms, "passes_ms": passes, "bytes_per_ray": BYTES_PER_RAY,
