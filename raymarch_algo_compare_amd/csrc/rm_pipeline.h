@@ -593,6 +593,7 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
                 const int gx = g.x0 + lane;
                 const bool col_ok = lane < g.tw;
                 long long bs = 0, bq = 0;
+                const bool want_bv = a.block_var != nullptr;      // (kernel-uniform)
                 // the three output bases are read from the kernel arguments once per tile, not once per row
                 float* o_depth = a.depth; int32_t* o_iters = a.iters; uint8_t* o_hit = a.hit;
                 pin_lane(o_depth); pin_lane(o_iters); pin_lane(o_hit);
@@ -610,11 +611,10 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
                             o_hit[gi] = (uint8_t)h;
                             acc.add(it, h);
                             atomicAdd(&s_hist[min(it, a.hist_bins - 1)], 1u);
-                            bs += it;
-                            bq += (long long)it * it;
+                            if (want_bv) { bs += it; bq += (long long)it * it; }
                         }
                     }
-                    if ((r & 3) == 3) {
+                    if ((r & 3) == 3 && want_bv) {
                         long long S = bs, Q = bq;
                         S += __shfl_xor(S, 1); Q += __shfl_xor(Q, 1);
                         S += __shfl_xor(S, 2); Q += __shfl_xor(Q, 2);
