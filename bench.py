@@ -379,7 +379,7 @@ def main():
                        "rays_per_step": int(rays_step),
                        "parallelism": (f"rowshard{world}-bandcyclic4+allgather" if wl["sharded"] else f"frame-per-gpu x{world}"),
                        "schedule": ("library defaults (RmFrameDesc knobs all 0): one launch per frame, tile order centre-out, rays struck "
-                                    "from their tile at 24 trips and handed to wavefront teams at 48, keep_busy on (finished producer "
+                                    "from their tile at 16 trips and handed to wavefront teams at 48 (near-surface rays at once), keep_busy on (finished producer "
                                     "workgroups execute fp32 filler until the teams are through: include/rm_hip.h)")
                                    if scene.id == 10 and not wl["sharded"] else "library defaults (RmFrameDesc knobs all 0)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -193,7 +193,11 @@ typedef struct RmFrameDesc {
      * (256 in launches that end with teams, off elsewhere: where other workgroups still render tiles the filler only
      * takes their issue slots), < 0 = off, > 0 = explicit burst length.  Results are identical for every setting. */
     int32_t keep_busy;
-    int32_t reserved0;
+    /* EARLY HAND-OVER (single launch, scenes with a team form and a per-evaluation cost measure: the Mandelbulb).  A ray that
+     * has been struck from its tile and whose last evaluation ran every iteration of the fractal loop -- a near-surface ray,
+     * eight producer turns per evaluation -- is handed to the teams at once instead of at suspend_after[1] trips.
+     * 0 = library default (on, from the strike budget), < 0 = off, > 0 = the earliest trip.  Results are identical. */
+    int32_t early_handover;
 } RmFrameDesc;
 
 /* Frame reduce computed in-kernel (the integer part of RayMarchStats.compute, core/types.py:77-137). */

@@ -214,6 +214,7 @@ int check_desc(const RmFrameDesc* d)
         return fail(RM_E_BAD_ARG, "bad single-launch tuning field");
     if (d->exit_backlog < 0 || d->late_teams > 65536) return fail(RM_E_BAD_ARG, "bad late-team field");
     if (d->keep_busy > (1 << 20)) return fail(RM_E_BAD_ARG, "keep_busy out of range");
+    if (d->early_handover > (1 << 20)) return fail(RM_E_BAD_ARG, "early_handover out of range");
     if (d->band_rows < 0 || d->band_stride < 0 || d->band_offset < 0) return fail(RM_E_BAD_ARG, "negative band parameter");
     if (d->band_rows > 0 && d->band_stride > 1) {
         const int th = d->tile_rows ? d->tile_rows : 4;
@@ -425,7 +426,7 @@ void suspend_levels(const RmFrameDesc* d, long long rays, int mode, int* park)
     // Gyroid (three sincos per evaluation, long skimming rays inside the ball) parked at 24 trips in round 1 (1.88 ->
     // 1.63 ms in natural tile order).  With the centre-out order its long rays start early anyway: parking measured
     // 1.63 vs 1.60 ms without (Adaptive-Hybrid 1.17 vs 1.05), so it no longer parks.
-    // Single launch (Mandelbulb): rays are struck from their tile at 24 trips (16 until round 3) (the tile slot is free again) and handed
+    // Single launch (Mandelbulb): rays are struck from their tile at 16 trips (the tile slot is free again) and handed
     // to the teams at 48; larger frames, and Segment whose trips evaluate twice, at 32 / 64.  Every strategy gains,
     // Overstep-Bisect and Skipping-Spheres included (3.56 -> 3.08 ms, 11.3 -> 10.2 ms).
     if (mode == 2 && d->scene_id == 10 && d->march.max_iterations > 128) {
@@ -433,10 +434,11 @@ void suspend_levels(const RmFrameDesc* d, long long rays, int mode, int* park)
         // 7.3-7.5 ms, 32 / 64 7.5-7.6, 16 / 48 8.5)
         const bool small = rays <= 3000000ll && d->strategy_id != 10 && d->tile_order_mode != 1;
         const bool ordered = rays <= 3000000ll && d->strategy_id != 10 && d->tile_order_mode == 1;
-        // (strike at 24 instead of 16, round 3: the same time over the Mandelbulb's three curated viewpoints x Standard / Enhanced /
-        // Adaptive-Hybrid -- sums 28.98 / 21.30 / 17.00 ms against 28.96 / 21.32 / 16.93, profiles/r03/viewpoint_budgets.jsonl -- and
-        // half as many rays finish outside their tile: 385 k instead of 738 k scattered 9-byte results per 1080p frame)
-        if (d->suspend_after[0] == 0) park[0] = small ? 24 : (ordered ? 24 : 32);
+        // (a strike at 24 measured the same as 16 over the Mandelbulb's three curated viewpoints x Standard / Enhanced / Adaptive-Hybrid
+        // -- sums 28.98 / 21.30 / 17.00 ms against 28.96 / 21.32 / 16.93, profiles/r03/viewpoint_budgets.jsonl)
+        // (with the early hand-over of near-surface rays the strike is back at 16: those rays leave the producer as soon as they
+        // are struck)
+        if (d->suspend_after[0] == 0) park[0] = small ? 16 : (ordered ? 24 : 32);
         if (d->suspend_after[1] == 0 && d->suspend_after[0] == 0) park[1] = small ? 48 : (ordered ? 56 : 64);
     }
     if (park[0] == 0) park[1] = 0;
@@ -668,6 +670,10 @@ int launch_frame(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, h
         // 9.4 -> 8.1 ms, Enhanced 7.0 -> 6.2 (burst 16 ... 2048 alike; fp64, fp32 and integer filler alike; s_sleep in the same
         // place: nothing).  Not with late teams, which need the producers' places.
         a.keep_busy = (teams && late == 0) ? (d->keep_busy > 0 ? d->keep_busy : (d->keep_busy == 0 ? 256 : 0)) : 0;
+        // EARLY HAND-OVER (rm_pipeline.h): struck near-surface rays go to the teams at once.  Over the Mandelbulb's three curated
+        // viewpoints at 1080p with the strike at 16: Standard 8.19 / 13.19 / 7.84 -> 7.81 / 13.02 / 7.81 ms, Enhanced 6.33 / 9.18 / 6.30
+        // -> 6.34 / 9.06 / 6.38 (sums -2.0 % / -0.1 %; strikes of 8 ... 24 alike, a regular hand-over later than 48 worse)
+        a.early_handover = (teams && detach_mode) ? (d->early_handover > 0 ? d->early_handover : (d->early_handover == 0 ? std::max(1, park[0]) : 0)) : 0;
         a.suspend_after2 = teams ? park[1] : 0;
         {
             int rc2;

@@ -326,6 +326,21 @@ __device__ __forceinline__ void store_direct(const KernelArgs& a, uint32_t gi, c
     }
 }
 
+// EARLY HAND-OVER (KernelArgs.early_handover, RmFrameDesc.early_handover).  A struck ray whose evaluation just took every trip
+// of the scene's inner loop (Scene::costly: the Mandelbulb's eight fractal iterations without a bail-out) is close to the
+// surface: it costs a producer eight turns per evaluation -- 15-32 us where a team needs 10 -- and it is the kind of ray that
+// runs long.  It goes to the teams at once instead of at suspend_after2; the others wait for that budget as before, so the
+// teams are not flooded (the plain budgets 16 / 32 or 24 / 40 were: DESIGN.md section 3).  Scenes without such a measure: never.
+template <class Scene, class E>
+__device__ __forceinline__ auto early_handover(const KernelArgs& a, const E& ev, int i) -> decltype(Scene::costly(ev), bool())
+{
+    return a.early_handover > 0 && i >= a.early_handover && Scene::costly(ev);
+}
+template <class Scene>
+__device__ __forceinline__ bool early_handover(const KernelArgs&, const NoEval&, int) { return false; }
+template <class Scene, class E>
+__device__ __forceinline__ bool early_handover(const KernelArgs&, const E&, long) { return false; }
+
 template <class Scene, class Strat, int TILE_H, bool INTERLEAVE, bool BATCH>
 __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const KernelArgs a)
 {
@@ -870,7 +885,7 @@ __global__ __launch_bounds__(64 * kPipeWaves, 2) void pipeline_kernel(const Kern
                     if (raw_out) store_raw(a, my_gi, s.res, nev);
                     acc.evals += (unsigned)nev;
                 }
-            } else if (!nopark && ((!resumed && park0 > 0 && s.i >= park0) || (resumed && park1 > 0 && (s.i >= park1 || leaving)))) {
+            } else if (!nopark && ((!resumed && park0 > 0 && s.i >= park0) || (resumed && park1 > 0 && (s.i >= park1 || leaving || early_handover<Scene>(a, ev, s.i))))) {
                 park = true;
             } else if constexpr (INTERLEAVE) {
                 ready = Scene::begin(ev, origin + dir * s.te);   // ray.py:15-17
