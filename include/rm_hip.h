@@ -196,7 +196,8 @@ typedef struct RmFrameDesc {
     /* EARLY HAND-OVER (single launch, scenes with a team form and a per-evaluation cost measure: the Mandelbulb).  A ray that
      * has been struck from its tile and whose last evaluation ran every iteration of the fractal loop -- a near-surface ray,
      * eight producer turns per evaluation -- is handed to the teams at once instead of at suspend_after[1] trips.
-     * 0 = library default (on, from the strike budget), < 0 = off, > 0 = the earliest trip.  Results are identical. */
+     * 0 = library default (on from the strike budget; off for Overstep-Bisect, Skipping-Spheres and Adaptive-Hybrid, which
+     * measured 1-2 % slower with it), < 0 = off, > 0 = the earliest trip.  Results are identical. */
     int32_t early_handover;
 } RmFrameDesc;
 

@@ -673,7 +673,12 @@ int launch_frame(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, h
         // EARLY HAND-OVER (rm_pipeline.h): struck near-surface rays go to the teams at once.  Over the Mandelbulb's three curated
         // viewpoints at 1080p with the strike at 16: Standard 8.19 / 13.19 / 7.84 -> 7.81 / 13.02 / 7.81 ms, Enhanced 6.33 / 9.18 / 6.30
         // -> 6.34 / 9.06 / 6.38 (sums -2.0 % / -0.1 %; strikes of 8 ... 24 alike, a regular hand-over later than 48 worse)
-        a.early_handover = (teams && detach_mode) ? (d->early_handover > 0 ? d->early_handover : (d->early_handover == 0 ? std::max(1, park[0]) : 0)) : 0;
+        // By strategy (default camera, on / off): Relaxed 7.90 / 8.36, Auto-Relaxed 7.92 / 8.19, Slope 6.67 / 7.10, Curvature 7.65 / 8.12,
+        // Segment 10.6 / 11.9, Safe-Relaxed 7.75 / 8.08; RevAA and Dense-March alike; the three whose rays end early or whose loop
+        // index restarts lose 1-2 % (Overstep-Bisect 3.09 / 3.03, Skipping-Spheres 8.77 / 8.66, Adaptive-Hybrid 4.74 / 4.69): off there.
+        const bool eh_default = d->strategy_id != 6 && d->strategy_id != 7 && d->strategy_id != 9;
+        a.early_handover = (teams && detach_mode)
+            ? (d->early_handover > 0 ? d->early_handover : (d->early_handover == 0 && eh_default ? std::max(1, park[0]) : 0)) : 0;
         a.suspend_after2 = teams ? park[1] : 0;
         {
             int rc2;
