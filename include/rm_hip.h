@@ -197,8 +197,12 @@ typedef struct RmFrameDesc {
      * has been struck from its tile and whose last evaluation ran every iteration of the fractal loop -- a near-surface ray,
      * eight producer turns per evaluation -- is handed to the teams at once instead of at suspend_after[1] trips.
      * 0 = library default (on from the strike budget; off for Overstep-Bisect, Skipping-Spheres and Adaptive-Hybrid, which
-     * measured 1-2 % slower with it), < 0 = off, > 0 = the earliest trip.  Results are identical. */
+     * measured 1-2 % slower with it), < 0 = off, > 0 = the earliest trip.  `early_trips`: the iterations an evaluation must
+     * have run to count as near-surface (0 = library default: 8 of 8; 1 ... 8 explicit -- 6 with suspend_after = {16, 64} is
+     * 1-8 % faster from two of the Mandelbulb's three curated cameras and writes half as much again to HBM).  Results are identical. */
     int32_t early_handover;
+    int32_t early_trips;
+    int32_t reserved1;
 } RmFrameDesc;
 
 /* Frame reduce computed in-kernel (the integer part of RayMarchStats.compute, core/types.py:77-137). */

@@ -110,7 +110,8 @@ class RmFrameDesc(ctypes.Structure):
                 ("team_steal", ctypes.c_int32), ("queue_refill_min", ctypes.c_int32), ("queue_retry", ctypes.c_int32),
                 ("team_retry", ctypes.c_int32), ("age_priority", ctypes.c_int32),
                 ("late_teams", ctypes.c_int32), ("exit_backlog", ctypes.c_int32),
-                ("keep_busy", ctypes.c_int32), ("early_handover", ctypes.c_int32)]
+                ("keep_busy", ctypes.c_int32), ("early_handover", ctypes.c_int32),
+                ("early_trips", ctypes.c_int32), ("reserved1", ctypes.c_int32)]
 
 
 class RmOutputs(ctypes.Structure):
@@ -260,7 +261,7 @@ def make_desc(scene_id, strategy_id, cam14, width, height, row0=0, rows=None, ma
               grid_waves=0, band_rows=0, band_stride=0, band_offset=0, tile_order_mode=0, eval_mode=0,
               suspend_after=(0, 0), resume_grid=0, resume_mode=0, params: dict | None = None, pipeline=0, team_grid=0,
               queue_first=0, team_steal=0, queue_refill_min=0, queue_retry=0, team_retry=0, age_priority=0, late_teams=0,
-              exit_backlog=0, keep_busy=0, early_handover=0) -> RmFrameDesc:
+              exit_backlog=0, keep_busy=0, early_handover=0, early_trips=0) -> RmFrameDesc:
     d = RmFrameDesc()
     d.scene_id, d.strategy_id = int(scene_id), int(strategy_id)
     d.width, d.height = int(width), int(height)
@@ -290,6 +291,7 @@ def make_desc(scene_id, strategy_id, cam14, width, height, row0=0, rows=None, ma
     d.late_teams, d.exit_backlog = int(late_teams), int(exit_backlog)
     d.keep_busy = int(keep_busy)
     d.early_handover = int(early_handover)
+    d.early_trips = int(early_trips)
     return d
 
 

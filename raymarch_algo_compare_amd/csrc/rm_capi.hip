@@ -215,6 +215,7 @@ int check_desc(const RmFrameDesc* d)
     if (d->exit_backlog < 0 || d->late_teams > 65536) return fail(RM_E_BAD_ARG, "bad late-team field");
     if (d->keep_busy > (1 << 20)) return fail(RM_E_BAD_ARG, "keep_busy out of range");
     if (d->early_handover > (1 << 20)) return fail(RM_E_BAD_ARG, "early_handover out of range");
+    if (d->early_trips < 0 || d->early_trips > 64) return fail(RM_E_BAD_ARG, "early_trips out of range");
     if (d->band_rows < 0 || d->band_stride < 0 || d->band_offset < 0) return fail(RM_E_BAD_ARG, "negative band parameter");
     if (d->band_rows > 0 && d->band_stride > 1) {
         const int th = d->tile_rows ? d->tile_rows : 4;
@@ -676,6 +677,12 @@ int launch_frame(const RmFrameDesc* d, rm::KernelArgs a, int tile_h, int grid, h
         // By strategy (default camera, on / off): Relaxed 7.90 / 8.36, Auto-Relaxed 7.92 / 8.19, Slope 6.67 / 7.10, Curvature 7.65 / 8.12,
         // Segment 10.6 / 11.9, Safe-Relaxed 7.75 / 8.08; RevAA and Dense-March alike; the three whose rays end early or whose loop
         // index restarts lose 1-2 % (Overstep-Bisect 3.09 / 3.03, Skipping-Spheres 8.77 / 8.66, Adaptive-Hybrid 4.74 / 4.69): off there.
+        // early_trips: how many of the eight fractal iterations make an evaluation "near-surface".  Six, together with a regular
+        // hand-over at 64 instead of 48 trips, measured Standard 7.75 / 11.81 / 7.96 ms against 7.85 / 12.88 / 7.77 from the three
+        // curated cameras (Auto-Relaxed 7.83 / 11.99 / 7.54 against 8.01 / 12.61 / 7.71; the bench line 266-270 Mrays/s instead of
+        // 261-264) -- but twice as many rays go through the queue: 88.9 MB of HBM traffic per frame instead of 58.2, for 1-2 % from
+        // the default camera and a loss from the angled one.  The default stays 8 of 8; the knob is there.
+        a.early_trips = d->early_trips > 0 ? d->early_trips : 8;
         const bool eh_default = d->strategy_id != 6 && d->strategy_id != 7 && d->strategy_id != 9;
         a.early_handover = (teams && detach_mode)
             ? (d->early_handover > 0 ? d->early_handover : (d->early_handover == 0 && eh_default ? std::max(1, park[0]) : 0)) : 0;

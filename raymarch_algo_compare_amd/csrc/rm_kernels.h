@@ -154,7 +154,8 @@ struct KernelArgs {
     int32_t team_prio;          // s_setprio level of the team waves (0..3)
     int32_t age_prio;           // > 0: a producer wave's issue priority = (trips of its oldest ray) / age_prio, capped at 2
     int32_t marks;              // single launch: waves leave device-clock marks in stats block 0 (rm_set_pass_timing); off in production
-    int32_t early_handover;     // single launch: > 0 = a struck ray at this trip or later whose evaluation was Scene::costly goes to the teams at once
+    int32_t early_handover;     // single launch: > 0 = a struck ray at this trip or later whose evaluation ran >= early_trips iterations
+    int32_t early_trips;        // (Scene::eval_trips) goes to the teams at once
     int32_t keep_busy;          // > 0: workgroups without work stay and execute this many fp32 fmas per lane between two looks at
                                 // the count of finished team workgroups (keep_busy_until below; RmFrameDesc.keep_busy)
     // Roles that change during the launch (rm_pipeline.h "late teams"): workgroups [late_team_first, gridDim.x) are teams

@@ -327,14 +327,15 @@ __device__ __forceinline__ void store_direct(const KernelArgs& a, uint32_t gi, c
 }
 
 // EARLY HAND-OVER (KernelArgs.early_handover, RmFrameDesc.early_handover).  A struck ray whose evaluation just took every trip
-// of the scene's inner loop (Scene::costly: the Mandelbulb's eight fractal iterations without a bail-out) is close to the
+// of the scene's inner loop (Scene::eval_trips against KernelArgs.early_trips: all eight fractal iterations of the Mandelbulb
+// without a bail-out, or six of them for the strategies that measured better so) is close to the
 // surface: it costs a producer eight turns per evaluation -- 15-32 us where a team needs 10 -- and it is the kind of ray that
 // runs long.  It goes to the teams at once instead of at suspend_after2; the others wait for that budget as before, so the
 // teams are not flooded (the plain budgets 16 / 32 or 24 / 40 were: DESIGN.md section 3).  Scenes without such a measure: never.
 template <class Scene, class E>
-__device__ __forceinline__ auto early_handover(const KernelArgs& a, const E& ev, int i) -> decltype(Scene::costly(ev), bool())
+__device__ __forceinline__ auto early_handover(const KernelArgs& a, const E& ev, int i) -> decltype(Scene::eval_trips(ev), bool())
 {
-    return a.early_handover > 0 && i >= a.early_handover && Scene::costly(ev);
+    return a.early_handover > 0 && i >= a.early_handover && Scene::eval_trips(ev) >= a.early_trips;
 }
 template <class Scene>
 __device__ __forceinline__ bool early_handover(const KernelArgs&, const NoEval&, int) { return false; }

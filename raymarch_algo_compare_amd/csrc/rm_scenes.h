@@ -158,8 +158,8 @@ struct SceneMandelbulb {                                                        
         e.r = length_a(p);
         return e.r > 4.0;
     }
-    // an evaluation that ran all eight iterations without a bail-out: the point is close to the set (rm_pipeline.h EARLY HAND-OVER)
-    static RM_HD bool costly(const Eval& e) { return e.i >= 8; }
+    // iterations the evaluation ran (8 = no bail-out: the point is close to the set; rm_pipeline.h EARLY HAND-OVER)
+    static RM_HD int eval_trips(const Eval& e) { return e.i; }
     // the body of one trip of `for i in range(8)` (:276-290) followed by the loop test and the next
     // trip's length / bailout test; needs r <= 4 and i < 8.  true when the loop has ended.  The loop
     // is rotated (test at the bottom) so that every trip a lane takes is a full update: an

@@ -42,7 +42,8 @@ def one_case(rng):
                  queue_refill_min=int(rng.choice([0, 1, 16, 64])), queue_retry=int(rng.choice([0, 1, 5, 100])),
                  team_retry=int(rng.choice([0, 1, 3, 50])), age_priority=int(rng.choice([0, 0, 1, 16, 40])),
                  late_teams=int(rng.choice([0, 0, 1, 3, 40])), exit_backlog=int(rng.choice([0, 1, 8, 500])),
-                 keep_busy=int(rng.choice([0, 0, -1, 1, 300])), early_handover=int(rng.choice([0, 0, -1, 1, 7, 60])))
+                 keep_busy=int(rng.choice([0, 0, -1, 1, 300])), early_handover=int(rng.choice([0, 0, -1, 1, 7, 60])),
+                 early_trips=int(rng.choice([0, 0, 1, 3, 6, 8])))
     prm = None
     if rng.random() < 0.3:                             # strategy parameters, the shader-only uniforms included
         prm = dict(omega=float(rng.choice([1.0, 1.2, 1.5, 1.9])), step_scale=float(rng.choice([1.0, 0.6, 0.5])),

@@ -15,7 +15,8 @@ KNOBS = [dict(), dict(team_grid=1), dict(team_grid=5, queue_first=2), dict(team_
          dict(grid_waves=4, team_grid=2), dict(grid_waves=1000, team_grid=64, refill_min=1), dict(resume_mode=1),
          dict(late_teams=3, team_grid=1), dict(late_teams=60, exit_backlog=1), dict(late_teams=5, exit_backlog=400, team_grid=2),
          dict(keep_busy=-1), dict(keep_busy=1, team_grid=2), dict(keep_busy=5000, grid_waves=1000, team_grid=3),
-         dict(early_handover=-1), dict(early_handover=1, team_grid=4), dict(early_handover=30, keep_busy=-1)]
+         dict(early_handover=-1), dict(early_handover=1, team_grid=4), dict(early_handover=30, keep_busy=-1),
+         dict(early_trips=1, early_handover=1), dict(early_trips=6), dict(early_trips=64, team_grid=2)]
 
 
 def test_mandelbulb_every_strategy_single_launch(hip):
