@@ -204,7 +204,14 @@ __device__ __forceinline__ bool q_push(const KernelArgs& a, int q, bool want, ui
             if (lane == p) { p0 = a0; p1 = a1; p2 = a2; p3 = a3; }
         }
         char* const d = (char*)((QEntry<Strat>*)a.queue[q] + (((unsigned long long)ihi << 32) | ilo)) + 16 * lane;
-        if (lane < NP) {
+        // The result record of the strategy (StratBase::res, entry bytes 48 .. 71) is dead until the ray finishes unless the frame
+        // asks for final_sdf (cfg.full: the tail evaluation runs AFTER the record is filled).  Its words are not stored then: piece
+        // 3 (res.t, res.final_sdf) never, piece 4 neither where it is only the record's last word (a 72-byte entry).  The reader
+        // copies whatever the slot holds into a field nobody reads before finish() overwrites it.
+        static_assert(std::is_base_of<StratBase, Strat>::value && __builtin_offsetof(StratBase, res) == 32 && sizeof(Result) == 24 &&
+                      sizeof(QEntry<StratBase>) - sizeof(StratBase) == 16, "entry pieces 3 and 4 hold the result record");
+        const bool dead = !a.full && (lane == 3 || (NW == 9 && lane == 4));
+        if (lane < NP && !dead) {
             if ((NW & 1) && lane == NP - 1) {
                 __hip_atomic_store((unsigned long long*)d, ((unsigned long long)p1 << 32) | p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {

@@ -49,16 +49,23 @@ def one_case(rng):
         prm = dict(omega=float(rng.choice([1.0, 1.2, 1.5, 1.9])), step_scale=float(rng.choice([1.0, 0.6, 0.5])),
                    dense_min_step=float(rng.choice([1e-4, 0.002, 0.02])), beta=float(rng.choice([0.3, 0.6])),
                    overstep_bisection_steps=int(rng.choice([16, 5])), margin=float(rng.choice([0.05, 0.15])))
-    desc = _native.make_desc(sid, kid, cam, w, h, row0, rows, mi, thr, far, lip, True, params=prm, **sched)
-    out = _native.render(desc, want_t_raw=True, want_final_sdf=True)
+    # one case in four takes the PRODUCT path (march.full = 0: no final_sdf, the strategy's result record is dead until the ray
+    # finishes and is not carried through the queues): depth instead of the raw fp64 t
+    full = bool(rng.random() < 0.75)
+    desc = _native.make_desc(sid, kid, cam, w, h, row0, rows, mi, thr, far, lip, full, params=prm, **sched)
+    out = _native.render(desc, want_t_raw=full, want_final_sdf=full)
     ref = oracle.render(sid, kid, cam, w, h, row0=row0, rows=rows, max_iterations=mi, hit_threshold=thr, max_distance=far, lipschitz=lip, params=prm)
+    if full:
+        same_t = ((out["t_raw"].view(np.uint64) == ref.t.view(np.uint64)).all()
+                  and (out["final_sdf"].view(np.uint64) == ref.final_sdf.view(np.uint64)).all())
+    else:
+        same_t = (out["depth"].view(np.uint32) == np.where(ref.hit > 0, ref.t, 0.0).astype(np.float32).view(np.uint32)).all()   # types.py:93
     ok = ((out["iters"] == ref.iters).all() and (out["hit"] == ref.hit).all()
-          and (out["t_raw"].view(np.uint64) == ref.t.view(np.uint64)).all()
-          and (out["final_sdf"].view(np.uint64) == ref.final_sdf.view(np.uint64)).all()
+          and same_t
           and out["stats"]["sum_iters"] == int(ref.iters.sum()) and out["stats"]["hit_count"] == int(ref.hit.sum())
           and out["stats"]["total_rays"] == ref.iters.size
           and (out["stats"]["iter_hist"] == np.bincount(ref.iters.ravel(), minlength=len(out["stats"]["iter_hist"]))).all())
-    return ok, dict(sid=sid, kid=kid, w=w, h=h, row0=row0, rows=rows, mi=mi, thr=thr, far=far, pos=pos, params=prm, **sched)
+    return ok, dict(sid=sid, kid=kid, w=w, h=h, row0=row0, rows=rows, mi=mi, thr=thr, far=far, pos=pos, params=prm, full=full, **sched)
 
 
 def main():
